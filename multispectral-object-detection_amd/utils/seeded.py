@@ -1,0 +1,85 @@
+"""Deterministic synthetic weights for tests and benchmarks.
+
+There are no trained CFT checkpoints offline (reference README.md:91-105 links
+Google-Drive weights), and the reference's default initialisation makes parity
+vacuous: BatchNorm running stats are the identity and ``GPT.pos_emb`` is zero
+(reference models/common.py:565).  ``seeded_state_dict`` fills every tensor of
+a reference-format ``state_dict`` from a per-key seeded CPU generator, scaled
+so activations stay O(1) through ~100 layers (a trained, BN-normalised network
+behaves that way).  The same function is applied to the reference model (when
+golden vectors are generated), to the CPU oracle and to the HIP model, so the
+three always hold identical fp32 weights without shipping a checkpoint.
+
+Pure CPU torch; no dependency on the HIP library or on ``oracle/``.
+"""
+import zlib
+
+import torch
+
+CONV_GAIN = 1.45     # keeps SiLU(conv(x)) at roughly unit second moment
+RES_CONV_GAIN = 0.25 # 3x3 conv inside residual Bottlenecks: slow the variance growth
+HEAD_GAIN = 0.4      # Detect 1x1 convs: keep raw logits at std ~1.5 so sigmoids are not saturated
+
+
+def _gen(seed, key):
+    g = torch.Generator(device="cpu")
+    g.manual_seed((int(seed) * 1000003 + zlib.crc32(key.encode())) % (2 ** 63 - 1))
+    return g
+
+
+def _randn(shape, g):
+    return torch.randn(shape, generator=g, dtype=torch.float32)
+
+
+def _rand(shape, g, lo, hi):
+    return torch.rand(shape, generator=g, dtype=torch.float32) * (hi - lo) + lo
+
+
+def seeded_tensor(key, ref, seed=0):
+    """Value for state-dict entry ``key`` whose shape/dtype is given by ``ref``."""
+    shape = tuple(ref.shape)
+    g = _gen(seed, key)
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked" or key.endswith("anchors") or key.endswith("anchor_grid"):
+        return ref.clone()
+    if leaf == "pos_emb":
+        return 0.3 * _randn(shape, g)
+    if leaf == "running_mean":
+        return 0.1 * _randn(shape, g)
+    if leaf == "running_var":
+        return _rand(shape, g, 0.5, 1.5)
+    is_norm = (".bn." in key) or (".ln_" in key) or (".ln_f." in key)
+    if is_norm and leaf == "weight":
+        return _rand(shape, g, 0.8, 1.2)
+    if leaf == "bias":
+        return 0.1 * _randn(shape, g)
+    if leaf == "weight" and len(shape) == 4:
+        fan_in = shape[1] * shape[2] * shape[3]
+        gain = CONV_GAIN
+        if ".conv." not in key:          # Detect head: model.<last>.m.<i>.weight
+            gain = HEAD_GAIN
+        # Bottleneck.cv2 (3x3) feeds a residual add: model.<i>.m.<j>.cv2.conv.weight
+        if ".m." in key and ".cv2." in key and shape[2] == 3:
+            gain = RES_CONV_GAIN
+        return _randn(shape, g) * (gain / fan_in ** 0.5)
+    if leaf == "weight" and len(shape) == 2:
+        return _randn(shape, g) * (1.0 / shape[1] ** 0.5)
+    return 0.1 * _randn(shape, g)
+
+
+def seeded_state_dict(template, seed=0):
+    """Return a new state dict with the keys/shapes of ``template`` (a reference-format
+    ``state_dict`` or ``{key: tensor}``), deterministically filled."""
+    out = {}
+    for k, v in template.items():
+        out[k] = seeded_tensor(k, v, seed).to(v.dtype) if v.is_floating_point() else v.clone()
+    return out
+
+
+def seeded_inputs(batch, height, width, seed=0):
+    """RGB and IR image batches in [0,1), the post-``/255`` range of reference test.py:107-108."""
+    g0 = torch.Generator(device="cpu"); g0.manual_seed(1000 + seed)
+    g1 = torch.Generator(device="cpu"); g1.manual_seed(2000 + seed)
+    rgb = torch.rand((batch, 3, height, width), generator=g0, dtype=torch.float32)
+    ir = torch.rand((batch, 3, height, width), generator=g1, dtype=torch.float32)
+    return rgb, ir

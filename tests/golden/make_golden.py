@@ -1,0 +1,93 @@
+"""Generate the golden vectors that pin ``oracle/cft_oracle.py`` to the reference.
+
+Runs ONLY in the build container (needs /root/reference).  It imports the reference's own
+``models.yolo_test.Model`` unmodified - with empty stand-in modules for the import-time-only
+dependencies that are missing from this image (cv2, torchvision, seaborn) -
+loads the deterministic synthetic weights of ``utils/seeded.py``, runs the reference
+forward on CPU fp32 and stores inputs' seeds, outputs and per-layer statistics.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.pt
+
+The cases cover: every fusion layout, s and l sizes, nc in {1,3,9}, square and rectangular
+inputs, batch > 1, BN-unfused and ``.fuse()``d forwards, and the derived BASELINE configs.
+"""
+import hashlib
+import logging
+import os
+import sys
+import types
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+# name, config name, batch, H, W, fused, seed
+CASES = [
+    ("s_add_320", "cfg1", 1, 320, 320, False, 0),
+    ("s_add_320_fused", "cfg1", 1, 320, 320, True, 0),
+    ("s_1cft_256", "cfg2", 2, 256, 256, True, 1),
+    ("s_x3_320", "yolov5s_fusion_transformerx3_vedai", 1, 320, 320, True, 2),
+    ("s_x3_rect", "yolov5s_fusion_transformerx3_vedai", 2, 192, 320, False, 3),
+    ("s_x4_256", "yolov5s_fusion_transformer_vedai", 1, 256, 256, True, 4),
+    ("l_x3_flir_256", "cfg3", 1, 256, 256, True, 5),
+    ("l_x3_llvip_192", "cfg4", 1, 192, 192, True, 6),
+]
+
+
+def install_reference():
+    for name in ("cv2", "torchvision", "seaborn"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["cv2"].setNumThreads = lambda n: None
+    sys.path.insert(0, REF)
+    logging.disable(logging.CRITICAL)
+
+
+def tap_stats(t):
+    """Compact, order-sensitive fingerprint of a feature map: moments + 32 strided samples."""
+    f = t.detach().float().reshape(-1)
+    idx = torch.linspace(0, f.numel() - 1, 32).long()
+    return {"shape": tuple(t.shape), "mean": f.mean().item(), "std": f.std().item(),
+            "absmax": f.abs().max().item(), "samples": f[idx].clone()}
+
+
+def main():
+    install_reference()
+    sys.path.insert(0, ROOT)
+    import msod_amd  # noqa: F401  (package alias; pure-python parts only)
+    from msod_amd.models.configs import named_config
+    from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict
+    from models.yolo_test import Model  # the reference
+
+    torch.set_num_threads(os.cpu_count())
+    for name, cfg_name, b, h, w, fused, seed in CASES:
+        cfg = named_config(cfg_name)
+        torch.manual_seed(0)
+        model = Model(cfg).eval()
+        model.load_state_dict(seeded_state_dict(model.state_dict(), seed))
+        if fused:
+            model.fuse()
+        rgb, ir = seeded_inputs(b, h, w, seed)
+        taps = {}
+        hooks = []
+        for i, m in enumerate(model.model):
+            if i in model.save and type(m).__name__ not in ("Detect", "GPT"):
+                hooks.append(m.register_forward_hook(lambda mod, inp, out, i=i: taps.__setitem__(i, tap_stats(out))))
+        with torch.no_grad():
+            pred, raw = model(rgb, ir)
+        for hk in hooks:
+            hk.remove()
+        blob = {
+            "case": dict(name=name, cfg=cfg_name, batch=b, height=h, width=w, fused=fused, seed=seed),
+            "torch": torch.__version__,
+            "pred": pred.clone(), "raw": [r.clone() for r in raw], "taps": taps,
+            "sha_rgb": hashlib.sha256(rgb.numpy().tobytes()).hexdigest(),
+        }
+        path = os.path.join(HERE, name + ".pt")
+        torch.save(blob, path)
+        print(f"{name:18s} pred {tuple(pred.shape)} raw std {raw[0].std():.3f} -> {os.path.getsize(path)/1e3:.0f} kB")
+
+
+if __name__ == "__main__":
+    main()
