@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""Headline benchmark: image-pairs/sec, forward only, yolov5l + CFTx3 (FLIR cfg), 640x640, batch 64
+per GPU, bf16 compute (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one forward of the whole two-stream network over one batch of synthetic pairs already
+resident in HBM (HIP-graph replay of every kernel, pre-NMS detections materialised), followed, for
+N > 1, by the RCCL all-gather of the detections.  Weak scaling: 64 pairs per GPU.  Rank 0 prints
+ONE JSON line; it also carries
+  roofline      the dominant kernel family (implicit-GEMM conv/linear, bf16 MFMA): algorithmic
+                FLOPs / summed launch time, each launch bracketed by HIP events on its stream
+  cpu_baseline  the CPU oracle (oracle/cft_oracle.py, a port of the reference forward to plain
+                torch fp32) timed on this box's host cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import msod_amd  # noqa: E402,F401
+from msod_amd import distributed as D  # noqa: E402
+from msod_amd import ops  # noqa: E402
+from msod_amd.models.configs import named_config  # noqa: E402
+from msod_amd.models.yolo_test import Model  # noqa: E402
+from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def gemm_family_time(model, rgb, ir):
+    """One eager forward with every GEMM launch bracketed by HIP events -> per-family totals."""
+    log = []
+    ops.set_launch_log(log)
+    try:
+        with torch.no_grad():
+            model.forward_once(rgb, ir)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_launch_log(None)
+    fam = {}
+    for name, flops, e0, e1 in log:
+        f = fam.setdefault(name, [0, 0.0, 0.0])
+        f[0] += 1
+        f[1] += flops
+        f[2] += e0.elapsed_time(e1) * 1e-3
+    n = sum(v[0] for v in fam.values())
+    flops = sum(v[1] for v in fam.values())
+    secs = sum(v[2] for v in fam.values())
+    return n, flops, secs, fam
+
+
+def cpu_baseline(cfg, sd, height, width, batch, iters):
+    """Reported baseline only: the oracle (port of the reference forward) on the host cores."""
+    from oracle.cft_oracle import OracleModel
+    torch.set_num_threads(os.cpu_count() or 1)
+    rgb, ir = seeded_inputs(batch, height, width, seed=0)
+    om = OracleModel(cfg)
+    om(sd, rgb[:1], ir[:1])
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        om(sd, rgb, ir)
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": batch / med, "unit": "image-pairs/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp32, yolov5l+CFTx3 {height}x{width}, batch {batch}, median of {iters} forwards "
+                      f"({med:.2f} s each)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="image pairs per GPU")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    cfg = named_config(args.config)
+    model = Model(cfg)
+    sd = seeded_state_dict(model.state_dict(), seed=0)      # random-init weights, BN/pos_emb non-trivial
+    model.load_state_dict(sd)
+    model = model.to(dev).fuse().set_compute_dtype(dtype)   # deployed form: BN folded (attempt_load does .fuse())
+    rgb, ir = seeded_inputs(args.batch, args.size, args.size, seed=rank)
+    rgb, ir = rgb.to(dev), ir.to(dev)
+
+    with torch.no_grad():
+        if args.no_graph:
+            step_fn = lambda: model.forward_once(rgb, ir)   # noqa: E731
+            pred, _ = step_fn()
+        else:
+            cap = model.capture(args.batch, args.size, args.size)
+            cap.rgb.copy_(rgb)
+            cap.ir.copy_(ir)
+            step_fn = cap.replay_static
+            pred, _ = step_fn()
+        gathered = None
+        if world > 1:
+            gathered = torch.empty((world * pred.shape[0],) + tuple(pred.shape[1:]), dtype=pred.dtype, device=dev)
+
+        def step():
+            p, _ = step_fn()
+            if world > 1:
+                D.gather_equal(p, gathered)
+
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(pred).all(), "non-finite detections"
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * args.batch * args.steps / elapsed
+        n_launch, flops, secs, fam = gemm_family_time(model, rgb, ir)
+        top = sorted(fam.items(), key=lambda kv: -kv[1][2])[:6]
+        peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+        achieved = flops / secs / 1e12
+        line = {
+            "metric": "image-pairs/sec fwd, yolov5l+CFTx3 640x640 bs64, 1/2/4/8 GPU",
+            "value": round(value, 2), "unit": "image-pairs/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.config}: yolov5l_fusion_transformerx3_FLIR_aligned two-stream forward, "
+                                   f"{args.size}x{args.size}, {args.batch} pairs/GPU, BN folded, pre-NMS detections",
+                       "pairs_per_gpu": args.batch, "image_size": args.size, "parallelism": f"batch-shard x{world}",
+                       "hip_graph": not args.no_graph},
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear family)",
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                         "traffic": None, "launches_per_step": n_launch,
+                         "avg_launch_us": round(secs / n_launch * 1e6, 2),
+                         "flops_per_step": flops, "gemm_time_share_of_step": round(secs * 1e3 / ms, 3),
+                         "top_shapes": [{"shape": k, "launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
+                                         "ms": round(v[2] * 1e3, 3)} for k, v in top]},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, {k: v for k, v in model.cpu().state_dict().items()},
+                                                args.size, args.size, batch=2, iters=3)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

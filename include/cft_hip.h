@@ -1,0 +1,141 @@
+/*
+ * cft_hip.h - C ABI of libcft_hip.so: the MI355X (gfx950) kernels behind the two-stream
+ * YOLOv5 + CFT inference forward.
+ *
+ * The reference (DocF/multispectral-object-detection) has no native code and no FFI: its hot
+ * path is Python nn.Modules dispatching to ATen.  Each entry point below therefore replaces
+ * the ATen call sequence of one reference module forward (file:line given per function,
+ * relative to /root/reference).  The Python modules in multispectral-object-detection_amd/
+ * models/common.py keep the reference's class names, constructor signatures and state-dict
+ * keys and call these functions through ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller; nothing is allocated or freed here;
+ *  - activations are NHWC ("channels-last"): element (b,y,x,c) of a tensor with `ld` channels
+ *    per pixel lives at ((b*H + y)*W + x)*ld + off + c, so a tensor may be a channel slice
+ *    [off, off+C) of a wider buffer (this is how Concat / C3 / SPP avoid copies);
+ *  - dtype codes: CFT_BF16 (bfloat16) or CFT_F32; `dtype` is the compute/activation type;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default);
+ *  - return value: CFT_OK (0) or a negative CFT_E* code; nothing is launched on error.
+ */
+#ifndef CFT_HIP_H
+#define CFT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { CFT_BF16 = 0, CFT_F32 = 1 };
+enum { CFT_ACT_NONE = 0, CFT_ACT_SILU = 1, CFT_ACT_GELU = 2 };
+enum {
+  CFT_OK = 0,
+  CFT_EINVAL = -1,   /* bad argument (alignment, size, dtype) */
+  CFT_ELAUNCH = -2,  /* HIP launch error */
+  CFT_ENODEV = -3    /* no gfx950 device / wrong architecture */
+};
+
+/* Library / device probe.  cft_abi_version() never touches the GPU. */
+int cft_abi_version(void);
+int cft_device_check(void);               /* CFT_OK iff the current device is gfx950 */
+const char* cft_last_error(void);
+
+/*
+ * Convolution as implicit GEMM with fused epilogue:
+ *   y[m, yoff+n] = act( sum_{kh,kw,ci} x[b, ho*s+kh-p, wo*s+kw-p, xoff+ci] * w[n][kh][kw][ci] + bias[n] )
+ *                  (+ res[m, roff+n] if res != NULL),   m = (b*Ho + ho)*Wo + wo,  p = k/2
+ * Replaces Conv.forward / Conv.fuseforward (models/common.py:45-50: conv2d + BatchNorm(eval,
+ * folded into w/bias, utils/torch_utils.py:181-201) + SiLU), the Bottleneck residual add
+ * (models/common.py:108-109), the channel concat of C3/SPP (via ldy/yoff; :142-143,:163-165),
+ * nn.Linear(+bias)(+GELU)(+residual) of the CFT block (models/common.py:450-453,532-546; call
+ * with B=1,H=1,W=rows,k=1) and the Detect 1x1 conv (models/yolo_test.py:46).
+ *   x    : dtype, NHWC, ldx channels per pixel, slice offset xoff, cin channels used
+ *   w    : dtype, [n][kpad] with (kh,kw,ci) flattened, ci fastest, zero padded to kpad
+ *          (kpad % 64 == 0 for bf16, % 32 == 0 for f32; cin % 8 (bf16) / % 4 (f32) == 0)
+ *   bias : float[n] or NULL
+ *   res  : residual, res_dtype, ldr/roff; NULL for none.  May alias y (same element).
+ *   y    : out_dtype, ldy/yoff.  n % 8 == 0, ldy % 8 == 0, yoff % 8 == 0.
+ */
+int cft_conv2d(const void* x, const void* w, const float* bias, const void* res, void* y,
+               int B, int H, int W, int cin, int ldx, int xoff,
+               int n, int kpad, int ksize, int stride,
+               int ldy, int yoff, int ldr, int roff,
+               int act, int dtype, int out_dtype, int res_dtype, void* stream);
+
+/*
+ * Focus space-to-depth (models/common.py:176-179, the torch.cat of four strided slices):
+ *   out[b, y, x, q*3 + c] = in[b, c, 2y+dy, 2x+dx],  q = dy + 2*dx, channels 12..15 = 0
+ * in : float NCHW [B,3,H,W] contiguous (the image batch, values in [0,1)); out : dtype NHWC
+ * [B,H/2,W/2,16].  The 3x3 Conv of Focus then runs through cft_conv2d with cin = 16.
+ */
+int cft_focus_s2d(const float* in, void* out, int B, int H, int W, int dtype, void* stream);
+
+/*
+ * SPP max pools (models/common.py:161-165): reads channels [0,C) of the NHWC buffer `buf`
+ * (ld channels/pixel) and writes max_pool2d(k, stride 1, pad k/2) for k = k1,k2,k3 to channel
+ * slices [C,2C), [2C,3C), [3C,4C) of the same buffer.  k odd, <= 13, k1 <= k2 <= k3.
+ */
+int cft_spp_maxpool(void* buf, int B, int H, int W, int C, int ld, int k1, int k2, int k3,
+                    int dtype, void* stream);
+
+/*
+ * Channel-slice copy with optional nearest-neighbour upsampling (nn.Upsample(None,2,'nearest')
+ * + Concat, yaml rows 33-34 / models/common.py:217-219):
+ *   out[b, y, x, ooff + c] = in[b, y >> up, x >> up, ioff + c],  c < C;  out is [B,Ho,Wo,ldo].
+ */
+int cft_copy_channels(const void* in, int ldi, int ioff, void* out, int ldo, int ooff,
+                      int B, int Ho, int Wo, int C, int up, int dtype, void* stream);
+
+/* Elementwise out = a + b over M pixels x C channels (Add / Add2, models/common.py:228-243). */
+int cft_add(const void* a, int lda, int aoff, const void* b, int ldb, int boff,
+            void* out, int ldo, int ooff, long M, int C, int dtype, void* stream);
+
+/*
+ * CFT tokeniser (models/common.py:608-621): AdaptiveAvgPool2d((8,8)) of both streams, flatten,
+ * concat on the token axis (RGB tokens 0..63, IR tokens 64..127), + pos_emb.
+ *   tokens[b, s*64 + i*8 + j, c] = mean(window(i,j) of stream s)[c] + pos_emb[s*64+i*8+j, c]
+ * window rows [floor(i*H/8), ceil((i+1)*H/8)).  rgb/ir: dtype NHWC; tokens: float [B,128,C].
+ */
+int cft_gpt_tokenize(const void* rgb, int ld_rgb, int off_rgb, const void* ir, int ld_ir, int off_ir,
+                     const float* pos_emb, float* tokens, int B, int H, int W, int C,
+                     int dtype, void* stream);
+
+/* LayerNorm over the last dim (eps 1e-5, affine; models/common.py:529-530,572):
+ * x float [rows, C] -> y out_dtype [rows, C]. */
+int cft_layernorm(const float* x, const float* gamma, const float* beta, void* y,
+                  long rows, int C, float eps, int out_dtype, void* stream);
+
+/*
+ * Multi-head self-attention core (models/common.py:491-510): for each (b, head)
+ *   O = softmax(Q K^T / sqrt(dk)) V  over T = 128 tokens.
+ * qkv : dtype [B*128, 3*heads*dkp]: row = token, columns [which(q,k,v)][head][dkp]; dkp is the
+ * head width padded with zeros to a multiple of 32 (bf16) / 16 (f32); dk the true head width.
+ * out : dtype [B*128, heads*dkp].
+ */
+int cft_attention(const void* qkv, void* out, int B, int heads, int dk, int dkp,
+                  int dtype, void* stream);
+
+/*
+ * CFT de-tokeniser fused with the residual add (models/common.py:626-637 + Add2 :238-243):
+ *   out[b,y,x,c] = (base ? base[b,y,x,c] : 0) + bilinear_{8x8 -> HxW, align_corners=False}(tokens[b, s*64 + ., c])
+ * tokens: float [B,128,C] (already through ln_f); s selects the stream (0 RGB, 1 IR).
+ */
+int cft_gpt_upsample_add(const float* tokens, int s, const void* base, int ldb, int boff,
+                         void* out, int ldo, int ooff, int B, int H, int W, int C,
+                         int dtype, void* stream);
+
+/*
+ * Detect decode (models/yolo_test.py:47-57).  logits: float [B,ny,nx,ldl] holding na*no valid
+ * channels (channel = a*no + o), the output of the 1x1 conv.  Writes
+ *   raw [B,na,ny,nx,no]            = logits permuted (the reference's x[i])
+ *   pred[B, row0 + (a*ny+y)*nx+x, o] with total_rows rows per image:
+ *        xy = (2*sig - 0.5 + grid) * stride,  wh = (2*sig)^2 * anchor[a],  rest = sig
+ * anchors: float[na*2] in pixels (anchor_grid of this level).
+ */
+int cft_detect_decode(const float* logits, int ldl, float* raw, float* pred, const float* anchors,
+                      int B, int ny, int nx, int na, int no, float stride,
+                      long row0, long total_rows, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFT_HIP_H */

@@ -1,0 +1,79 @@
+"""ctypes binding of ``libcft_hip.so`` (C ABI declared in ``include/cft_hip.h``).
+
+There is deliberately NO fallback: if the library is missing or the device is not gfx950 every
+op raises.  ``build()`` compiles the library in-tree with hipcc (cross-compiles without a GPU).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcft_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ("runtime.hip", "conv_gemm.hip", "pointwise.hip", "attention.hip")
+
+CFT_BF16, CFT_F32 = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+
+_c = ctypes
+_vp, _i, _l, _f = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float
+
+# name -> argtypes; every function returns int except cft_last_error.  Mirrors include/cft_hip.h.
+SIGNATURES = {
+    "cft_abi_version": [],
+    "cft_device_check": [],
+    "cft_conv2d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_focus_s2d": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "cft_spp_maxpool": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_copy_channels": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_add": [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _l, _i, _i, _vp],
+    "cft_gpt_tokenize": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "cft_layernorm": [_vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp],
+    "cft_attention": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "cft_gpt_upsample_add": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_detect_decode": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _l, _vp],
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into ``libcft_hip.so`` next to this file."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    newest = max(os.path.getmtime(p) for p in srcs + [os.path.join(CSRC, "cft_common.h"),
+                                                       os.path.join(_HERE, "..", "include", "cft_hip.h")])
+    if os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    global _lib
+    _lib = None
+    return LIB_PATH
+
+
+def load():
+    """Return the loaded library (cached).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP kernels are the only execution path of this package. "
+            "Build them with `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch, let it propagate
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.cft_last_error.argtypes = []
+    lib.cft_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().cft_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (status {status}): {msg}")

@@ -1,0 +1,82 @@
+// Shared device/host helpers for the gfx950 kernels of libcft_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cft_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// One 16-byte granule: 8 bf16 or 4 f32.  All NHWC tensors are addressed in granules.
+typedef __attribute__((ext_vector_type(4))) uint32_t gran_t;
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest-even, NaN kept quiet
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// Element traits: T = uint16_t (bf16 bits) or float.
+template <typename T> struct Elem;
+template <> struct Elem<uint16_t> {
+  static constexpr int GE = 8;   // elements per 16-byte granule
+  static __device__ __forceinline__ void unpack(const gran_t& g, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(g[i] << 16); f[2 * i + 1] = __uint_as_float(g[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ gran_t pack(const float* f) {
+    gran_t g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    return g;
+  }
+};
+template <> struct Elem<float> {
+  static constexpr int GE = 4;
+  static __device__ __forceinline__ void unpack(const gran_t& g, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(g[i]);
+  }
+  static __device__ __forceinline__ gran_t pack(const float* f) {
+    gran_t g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[i] = __float_as_uint(f[i]);
+    return g;
+  }
+};
+
+// One MFMA K-step on a pair of 16-byte granules (lane l: row l&15, k-group l>>4).
+// bf16: v_mfma_f32_16x16x32_bf16; f32: 4 x v_mfma_f32_16x16x4_f32 (exact fp32 products).
+// A and B use the same (k-group, element) -> k assignment, so any internal k order cancels.
+template <typename T>
+__device__ __forceinline__ f32x4_t mma_granule(const gran_t& a, const gran_t& b, f32x4_t c);
+
+template <>
+__device__ __forceinline__ f32x4_t mma_granule<uint16_t>(const gran_t& a, const gran_t& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t mma_granule<float>(const gran_t& a, const gran_t& b, f32x4_t c) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+  return c;
+}
+
+// ---- host side -----------------------------------------------------------------------------
+void cft_set_error(const char* msg);
+int cft_check_launch(const char* what);
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+#define CFT_REQUIRE(cond, msg)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      cft_set_error(msg);                 \
+      return CFT_EINVAL;                  \
+    }                                     \
+  } while (0)

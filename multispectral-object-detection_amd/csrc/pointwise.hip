@@ -1,0 +1,431 @@
+// Bandwidth-bound kernels of the two-stream YOLOv5 + CFT forward (gfx950): Focus space-to-depth,
+// SPP max pools, nearest-upsample/concat copy, Add/Add2, CFT tokeniser (adaptive avg-pool +
+// pos_emb), LayerNorm, CFT de-tokeniser (bilinear upsample + residual add) and Detect decode.
+// All tensors are NHWC and are moved in 16-byte granules (8 bf16 / 4 f32) per lane so that a
+// wave's accesses coalesce into full 128-B lines.
+#include "cft_common.h"
+
+static inline int grid_for(long work, int block) {
+  long g = (work + block - 1) / block;
+  const long cap = 256L * 16;  // 256 CUs x 16 resident 256-thread blocks; grid-stride beyond that
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ------------------------------------------------------------------------------- Focus
+// One thread per output pixel: 3 channels x (2 rows x float2) in, 16 channels out.
+template <typename T>
+__global__ void __launch_bounds__(256) focus_s2d_kernel(const float* __restrict__ in, unsigned char* __restrict__ out,
+                                                        int B, int H, int W) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long total = (long)B * Ho * Wo;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % Wo);
+    const long t = idx / Wo;
+    const int y = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* base = in + (((long)b * 3 + c) * H + 2 * y) * W + 2 * x;
+      const float2 top = *reinterpret_cast<const float2*>(base);
+      const float2 bot = *reinterpret_cast<const float2*>(base + W);
+      v[0 + c] = top.x;   // (dy=0, dx=0)
+      v[3 + c] = bot.x;   // (dy=1, dx=0)
+      v[6 + c] = top.y;   // (dy=0, dx=1)
+      v[9 + c] = bot.y;   // (dy=1, dx=1)
+    }
+    v[12] = v[13] = v[14] = v[15] = 0.f;
+    constexpr int GE = Elem<T>::GE;
+    gran_t* o = reinterpret_cast<gran_t*>(out + idx * 16 * sizeof(T));
+#pragma unroll
+    for (int k = 0; k < 16 / GE; ++k) o[k] = Elem<T>::pack(v + k * GE);
+  }
+}
+
+extern "C" int cft_focus_s2d(const float* in, void* out, int B, int H, int W, int dtype, void* stream) {
+  CFT_REQUIRE(in && out, "cft_focus_s2d: null pointer");
+  CFT_REQUIRE(B > 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0), "cft_focus_s2d: H and W must be even");
+  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_focus_s2d: bad dtype");
+  const long total = (long)B * (H / 2) * (W / 2);
+  const int grid = grid_for(total, 256);
+  if (dtype == CFT_BF16)
+    hipLaunchKernelGGL(focus_s2d_kernel<uint16_t>, dim3(grid), dim3(256), 0, as_stream(stream), in, (unsigned char*)out, B, H, W);
+  else
+    hipLaunchKernelGGL(focus_s2d_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), in, (unsigned char*)out, B, H, W);
+  return cft_check_launch("focus_s2d_kernel");
+}
+
+// ------------------------------------------------------------------------------- SPP
+// One workgroup per (image, 16-byte channel granule).  The HxW plane of that granule is staged
+// in LDS, then two separable passes (row maxima for the three radii, then column maxima).
+template <typename T>
+__device__ __forceinline__ void gmax(float* a, const gran_t& g) {
+  float f[Elem<T>::GE];
+  Elem<T>::unpack(g, f);
+#pragma unroll
+  for (int i = 0; i < Elem<T>::GE; ++i) a[i] = fmaxf(a[i], f[i]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) spp_maxpool_kernel(unsigned char* buf, int H, int W, int C, int ld,
+                                                          int r1, int r2, int r3) {
+  constexpr int GE = Elem<T>::GE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  gran_t* plane = reinterpret_cast<gran_t*>(smem);   // [H*W]
+  gran_t* rowm = plane + H * W;                      // [3][H*W]
+  const int gpc = C / GE;
+  const int b = blockIdx.x / gpc, cg = blockIdx.x % gpc;
+  const int HW = H * W;
+  unsigned char* base = buf + ((long)b * HW * ld + (long)cg * GE) * sizeof(T);
+  const long pix_stride = (long)ld * sizeof(T);
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) plane[i] = *reinterpret_cast<const gran_t*>(base + i * pix_stride);
+  __syncthreads();
+  const int rad[3] = {r1, r2, r3};
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const int y = i / W, x = i - y * W;
+    float m[GE];
+#pragma unroll
+    for (int e = 0; e < GE; ++e) m[e] = -INFINITY;
+    int done = -1;  // radius already covered
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      for (int d = done + 1; d <= rad[k]; ++d) {
+        if (d == 0) { gmax<T>(m, plane[i]); continue; }
+        if (x - d >= 0) gmax<T>(m, plane[i - d]);
+        if (x + d < W) gmax<T>(m, plane[i + d]);
+      }
+      done = rad[k];
+      rowm[k * HW + i] = Elem<T>::pack(m);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const int y = i / W;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float m[GE];
+#pragma unroll
+      for (int e = 0; e < GE; ++e) m[e] = -INFINITY;
+      const gran_t* src = rowm + k * HW;
+      for (int d = -rad[k]; d <= rad[k]; ++d)
+        if ((unsigned)(y + d) < (unsigned)H) gmax<T>(m, src[i + d * W]);
+      *reinterpret_cast<gran_t*>(base + i * pix_stride + (long)(k + 1) * C * sizeof(T)) = Elem<T>::pack(m);
+    }
+  }
+}
+
+extern "C" int cft_spp_maxpool(void* buf, int B, int H, int W, int C, int ld, int k1, int k2, int k3,
+                               int dtype, void* stream) {
+  CFT_REQUIRE(buf != nullptr, "cft_spp_maxpool: null pointer");
+  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_spp_maxpool: bad dtype");
+  const int ge = dtype == CFT_BF16 ? 8 : 4;
+  CFT_REQUIRE(C % ge == 0 && ld % ge == 0 && ld >= 4 * C, "cft_spp_maxpool: C/ld not granule aligned or ld < 4C");
+  CFT_REQUIRE((k1 & 1) && (k2 & 1) && (k3 & 1) && k1 <= k2 && k2 <= k3 && k3 <= 13 && k1 >= 1, "cft_spp_maxpool: kernel sizes must be odd, ascending, <= 13");
+  const size_t smem = (size_t)4 * H * W * 16;
+  CFT_REQUIRE(smem <= 160 * 1024, "cft_spp_maxpool: feature map too large for the LDS plane (H*W <= 2560)");
+  const int grid = B * (C / ge);
+  if (dtype == CFT_BF16) {
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spp_maxpool_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    hipLaunchKernelGGL(spp_maxpool_kernel<uint16_t>, dim3(grid), dim3(256), smem, as_stream(stream), (unsigned char*)buf, H, W, C, ld, k1 / 2, k2 / 2, k3 / 2);
+  } else {
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spp_maxpool_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    hipLaunchKernelGGL(spp_maxpool_kernel<float>, dim3(grid), dim3(256), smem, as_stream(stream), (unsigned char*)buf, H, W, C, ld, k1 / 2, k2 / 2, k3 / 2);
+  }
+  return cft_check_launch("spp_maxpool_kernel");
+}
+
+// ------------------------------------------------------------------------------- copy / upsample
+__global__ void __launch_bounds__(256) copy_channels_kernel(const unsigned char* __restrict__ in, long ldi_b, long ioff_b,
+                                                            unsigned char* __restrict__ out, long ldo_b, long ooff_b,
+                                                            int B, int Ho, int Wo, int gpp, int up) {
+  const long total = (long)B * Ho * Wo * gpp;
+  const int Hi = Ho >> up, Wi = Wo >> up;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int gidx = (int)(idx % gpp);
+    long t = idx / gpp;
+    const int x = (int)(t % Wo); t /= Wo;
+    const int y = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const long ipix = ((long)b * Hi + (y >> up)) * Wi + (x >> up);
+    const long opix = ((long)b * Ho + y) * Wo + x;
+    *reinterpret_cast<gran_t*>(out + opix * ldo_b + ooff_b + gidx * 16L) =
+        *reinterpret_cast<const gran_t*>(in + ipix * ldi_b + ioff_b + gidx * 16L);
+  }
+}
+
+extern "C" int cft_copy_channels(const void* in, int ldi, int ioff, void* out, int ldo, int ooff,
+                                 int B, int Ho, int Wo, int C, int up, int dtype, void* stream) {
+  CFT_REQUIRE(in && out, "cft_copy_channels: null pointer");
+  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_copy_channels: bad dtype");
+  const int ge = dtype == CFT_BF16 ? 8 : 4, es = dtype == CFT_BF16 ? 2 : 4;
+  CFT_REQUIRE(C % ge == 0 && ldi % ge == 0 && ioff % ge == 0 && ldo % ge == 0 && ooff % ge == 0, "cft_copy_channels: not granule aligned");
+  CFT_REQUIRE(up >= 0 && up <= 3 && (Ho % (1 << up) == 0) && (Wo % (1 << up) == 0), "cft_copy_channels: bad upsample shift");
+  const int gpp = C / ge;
+  const long total = (long)B * Ho * Wo * gpp;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream),
+                     (const unsigned char*)in, (long)ldi * es, (long)ioff * es, (unsigned char*)out, (long)ldo * es, (long)ooff * es,
+                     B, Ho, Wo, gpp, up);
+  return cft_check_launch("copy_channels_kernel");
+}
+
+// ------------------------------------------------------------------------------- add
+template <typename T>
+__global__ void __launch_bounds__(256) add_kernel(const unsigned char* a, long lda_b, long aoff_b,
+                                                  const unsigned char* b, long ldb_b, long boff_b,
+                                                  unsigned char* out, long ldo_b, long ooff_b, long M, int gpp) {
+  constexpr int GE = Elem<T>::GE;
+  const long total = M * gpp;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long m = idx / gpp;
+    const long go = (idx - m * gpp) * 16L;
+    float fa[GE], fb[GE];
+    Elem<T>::unpack(*reinterpret_cast<const gran_t*>(a + m * lda_b + aoff_b + go), fa);
+    Elem<T>::unpack(*reinterpret_cast<const gran_t*>(b + m * ldb_b + boff_b + go), fb);
+#pragma unroll
+    for (int e = 0; e < GE; ++e) fa[e] += fb[e];
+    *reinterpret_cast<gran_t*>(out + m * ldo_b + ooff_b + go) = Elem<T>::pack(fa);
+  }
+}
+
+extern "C" int cft_add(const void* a, int lda, int aoff, const void* b, int ldb, int boff,
+                       void* out, int ldo, int ooff, long M, int C, int dtype, void* stream) {
+  CFT_REQUIRE(a && b && out, "cft_add: null pointer");
+  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_add: bad dtype");
+  const int ge = dtype == CFT_BF16 ? 8 : 4, es = dtype == CFT_BF16 ? 2 : 4;
+  CFT_REQUIRE(C % ge == 0 && lda % ge == 0 && aoff % ge == 0 && ldb % ge == 0 && boff % ge == 0 && ldo % ge == 0 && ooff % ge == 0,
+              "cft_add: not granule aligned");
+  const int gpp = C / ge;
+  const int grid = grid_for(M * gpp, 256);
+  if (dtype == CFT_BF16)
+    hipLaunchKernelGGL(add_kernel<uint16_t>, dim3(grid), dim3(256), 0, as_stream(stream), (const unsigned char*)a, (long)lda * es, (long)aoff * es,
+                       (const unsigned char*)b, (long)ldb * es, (long)boff * es, (unsigned char*)out, (long)ldo * es, (long)ooff * es, M, gpp);
+  else
+    hipLaunchKernelGGL(add_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const unsigned char*)a, (long)lda * es, (long)aoff * es,
+                       (const unsigned char*)b, (long)ldb * es, (long)boff * es, (unsigned char*)out, (long)ldo * es, (long)ooff * es, M, gpp);
+  return cft_check_launch("add_kernel");
+}
+
+// ------------------------------------------------------------------------------- CFT tokeniser
+// grid = B*128 token cells; each thread owns channel granules and walks the pooling window.
+template <typename T>
+__global__ void __launch_bounds__(256) gpt_tokenize_kernel(const unsigned char* rgb, long ld_rgb_b, long off_rgb_b,
+                                                           const unsigned char* ir, long ld_ir_b, long off_ir_b,
+                                                           const float* __restrict__ pos_emb, float* __restrict__ tokens,
+                                                           int H, int W, int C) {
+  constexpr int GE = Elem<T>::GE;
+  const int cell = blockIdx.x & 127, b = blockIdx.x >> 7;
+  const int s = cell >> 6, i = (cell >> 3) & 7, j = cell & 7;
+  const int h0 = (i * H) / 8, h1 = ((i + 1) * H + 7) / 8;
+  const int w0 = (j * W) / 8, w1 = ((j + 1) * W + 7) / 8;
+  const unsigned char* src = s ? ir : rgb;
+  const long ldb = s ? ld_ir_b : ld_rgb_b, offb = s ? off_ir_b : off_rgb_b;
+  const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+  for (int cg = threadIdx.x; cg < C / GE; cg += blockDim.x) {
+    float acc[GE];
+#pragma unroll
+    for (int e = 0; e < GE; ++e) acc[e] = 0.f;
+    for (int y = h0; y < h1; ++y)
+      for (int x = w0; x < w1; ++x) {
+        float f[GE];
+        Elem<T>::unpack(*reinterpret_cast<const gran_t*>(src + (((long)b * H + y) * W + x) * ldb + offb + cg * 16L), f);
+#pragma unroll
+        for (int e = 0; e < GE; ++e) acc[e] += f[e];
+      }
+    float* o = tokens + ((long)b * 128 + cell) * C + cg * GE;
+    const float* pe = pos_emb + (long)cell * C + cg * GE;
+#pragma unroll
+    for (int e = 0; e < GE; ++e) o[e] = acc[e] * inv + pe[e];
+  }
+}
+
+extern "C" int cft_gpt_tokenize(const void* rgb, int ld_rgb, int off_rgb, const void* ir, int ld_ir, int off_ir,
+                                const float* pos_emb, float* tokens, int B, int H, int W, int C,
+                                int dtype, void* stream) {
+  CFT_REQUIRE(rgb && ir && pos_emb && tokens, "cft_gpt_tokenize: null pointer");
+  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_gpt_tokenize: bad dtype");
+  const int ge = dtype == CFT_BF16 ? 8 : 4, es = dtype == CFT_BF16 ? 2 : 4;
+  CFT_REQUIRE(C % ge == 0 && ld_rgb % ge == 0 && off_rgb % ge == 0 && ld_ir % ge == 0 && off_ir % ge == 0, "cft_gpt_tokenize: not granule aligned");
+  CFT_REQUIRE(B > 0 && H >= 1 && W >= 1, "cft_gpt_tokenize: bad shape");
+  int threads = C / ge;
+  threads = threads < 64 ? 64 : (threads > 256 ? 256 : ((threads + 63) / 64) * 64);
+  if (dtype == CFT_BF16)
+    hipLaunchKernelGGL(gpt_tokenize_kernel<uint16_t>, dim3(B * 128), dim3(threads), 0, as_stream(stream), (const unsigned char*)rgb, (long)ld_rgb * es, (long)off_rgb * es,
+                       (const unsigned char*)ir, (long)ld_ir * es, (long)off_ir * es, pos_emb, tokens, H, W, C);
+  else
+    hipLaunchKernelGGL(gpt_tokenize_kernel<float>, dim3(B * 128), dim3(threads), 0, as_stream(stream), (const unsigned char*)rgb, (long)ld_rgb * es, (long)off_rgb * es,
+                       (const unsigned char*)ir, (long)ld_ir * es, (long)off_ir * es, pos_emb, tokens, H, W, C);
+  return cft_check_launch("gpt_tokenize_kernel");
+}
+
+// ------------------------------------------------------------------------------- LayerNorm
+// One wave64 per row (C <= 64*32 floats kept in registers as float4 chunks), 4 rows per workgroup.
+template <int MAXV>
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, unsigned char* __restrict__ y,
+                                                        long rows, int C, float eps, int out_f32) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = C >> 2;  // float4 per row
+  const float4* xr = reinterpret_cast<const float4*>(x + row * C);
+  float4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int idx = lane + k * 64;
+    v[k] = idx < nv ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += v[k].x + v[k].y + v[k].z + v[k].w;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int idx = lane + k * 64;
+    if (idx < nv) {
+      const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+      q += a * a + b * b + c * c + d * d;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int idx = lane + k * 64;
+    if (idx < nv) {
+      const float4 gm = reinterpret_cast<const float4*>(gamma)[idx];
+      const float4 bt = reinterpret_cast<const float4*>(beta)[idx];
+      float o[4] = {(v[k].x - mean) * rstd * gm.x + bt.x, (v[k].y - mean) * rstd * gm.y + bt.y,
+                    (v[k].z - mean) * rstd * gm.z + bt.z, (v[k].w - mean) * rstd * gm.w + bt.w};
+      if (out_f32) {
+        *reinterpret_cast<float4*>(y + (row * C + idx * 4L) * 4) = *reinterpret_cast<float4*>(o);
+      } else {
+        uint2 pk;
+        pk.x = pack_bf16x2(o[0], o[1]);
+        pk.y = pack_bf16x2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(y + (row * C + idx * 4L) * 2) = pk;
+      }
+    }
+  }
+}
+
+extern "C" int cft_layernorm(const float* x, const float* gamma, const float* beta, void* y,
+                             long rows, int C, float eps, int out_dtype, void* stream) {
+  CFT_REQUIRE(x && gamma && beta && y, "cft_layernorm: null pointer");
+  CFT_REQUIRE(C % 4 == 0 && C >= 4 && C <= 4096, "cft_layernorm: C must be a multiple of 4 and <= 4096");
+  CFT_REQUIRE(out_dtype == CFT_BF16 || out_dtype == CFT_F32, "cft_layernorm: bad out dtype");
+  CFT_REQUIRE(rows > 0, "cft_layernorm: rows must be positive");
+  const int grid = (int)((rows + 3) / 4);
+  const int nv = C / 4;
+  const int of32 = out_dtype == CFT_F32;
+  if (nv <= 64 * 2)
+    hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, as_stream(stream), x, gamma, beta, (unsigned char*)y, rows, C, eps, of32);
+  else if (nv <= 64 * 5)
+    hipLaunchKernelGGL(layernorm_kernel<5>, dim3(grid), dim3(256), 0, as_stream(stream), x, gamma, beta, (unsigned char*)y, rows, C, eps, of32);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<16>, dim3(grid), dim3(256), 0, as_stream(stream), x, gamma, beta, (unsigned char*)y, rows, C, eps, of32);
+  return cft_check_launch("layernorm_kernel");
+}
+
+// ------------------------------------------------------------------------------- CFT de-tokeniser
+// out = base + bilinear(tokens 8x8 -> HxW), PyTorch align_corners=False source index:
+// src = (dst + 0.5) * (8 / size) - 0.5, clamped at 0; neighbour clamped at 7.
+template <typename T>
+__global__ void __launch_bounds__(256) gpt_upsample_add_kernel(const float* __restrict__ tokens, int s,
+                                                               const unsigned char* base, long ldb_b, long boff_b,
+                                                               unsigned char* out, long ldo_b, long ooff_b,
+                                                               int B, int H, int W, int C) {
+  constexpr int GE = Elem<T>::GE;
+  const int gpp = C / GE;
+  const long total = (long)B * H * W * gpp;
+  const float sy = 8.0f / (float)H, sx = 8.0f / (float)W;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % gpp);
+    long t = idx / gpp;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    float fy = ((float)y + 0.5f) * sy - 0.5f; fy = fy < 0.f ? 0.f : fy;
+    float fx = ((float)x + 0.5f) * sx - 0.5f; fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < 7 ? 1 : 0), x1 = x0 + (x0 < 7 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* tb = tokens + ((long)b * 128 + s * 64) * C + cg * GE;
+    const float* p00 = tb + (long)(y0 * 8 + x0) * C;
+    const float* p01 = tb + (long)(y0 * 8 + x1) * C;
+    const float* p10 = tb + (long)(y1 * 8 + x0) * C;
+    const float* p11 = tb + (long)(y1 * 8 + x1) * C;
+    float v[GE];
+    const long pix = ((long)b * H + y) * W + x;
+    if (base != nullptr) {
+      Elem<T>::unpack(*reinterpret_cast<const gran_t*>(base + pix * ldb_b + boff_b + cg * 16L), v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < GE; ++e) v[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < GE; ++e) v[e] += hy * (hx * p00[e] + lx * p01[e]) + ly * (hx * p10[e] + lx * p11[e]);
+    *reinterpret_cast<gran_t*>(out + pix * ldo_b + ooff_b + cg * 16L) = Elem<T>::pack(v);
+  }
+}
+
+extern "C" int cft_gpt_upsample_add(const float* tokens, int s, const void* base, int ldb, int boff,
+                                    void* out, int ldo, int ooff, int B, int H, int W, int C,
+                                    int dtype, void* stream) {
+  CFT_REQUIRE(tokens && out, "cft_gpt_upsample_add: null pointer");
+  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_gpt_upsample_add: bad dtype");
+  CFT_REQUIRE(s == 0 || s == 1, "cft_gpt_upsample_add: stream index must be 0 or 1");
+  const int ge = dtype == CFT_BF16 ? 8 : 4, es = dtype == CFT_BF16 ? 2 : 4;
+  CFT_REQUIRE(C % ge == 0 && ldo % ge == 0 && ooff % ge == 0 && (base == nullptr || (ldb % ge == 0 && boff % ge == 0)), "cft_gpt_upsample_add: not granule aligned");
+  const long total = (long)B * H * W * (C / ge);
+  const int grid = grid_for(total, 256);
+  if (dtype == CFT_BF16)
+    hipLaunchKernelGGL(gpt_upsample_add_kernel<uint16_t>, dim3(grid), dim3(256), 0, as_stream(stream), tokens, s, (const unsigned char*)base, (long)ldb * es, (long)boff * es,
+                       (unsigned char*)out, (long)ldo * es, (long)ooff * es, B, H, W, C);
+  else
+    hipLaunchKernelGGL(gpt_upsample_add_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), tokens, s, (const unsigned char*)base, (long)ldb * es, (long)boff * es,
+                       (unsigned char*)out, (long)ldo * es, (long)ooff * es, B, H, W, C);
+  return cft_check_launch("gpt_upsample_add_kernel");
+}
+
+// ------------------------------------------------------------------------------- Detect decode
+__global__ void __launch_bounds__(256) detect_decode_kernel(const float* __restrict__ logits, int ldl, float* __restrict__ raw,
+                                                            float* __restrict__ pred, const float* __restrict__ anchors,
+                                                            int B, int ny, int nx, int na, int no, float stride,
+                                                            long row0, long total_rows) {
+  const long total = (long)B * na * ny * nx * no;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int o = (int)(idx % no);
+    long t = idx / no;
+    const int x = (int)(t % nx); t /= nx;
+    const int y = (int)(t % ny); t /= ny;
+    const int a = (int)(t % na);
+    const int b = (int)(t / na);
+    const float v = logits[(((long)b * ny + y) * nx + x) * ldl + a * no + o];
+    raw[idx] = v;
+    const float sg = 1.0f / (1.0f + __expf(-v));
+    float r;
+    if (o == 0) r = (sg * 2.0f - 0.5f + (float)x) * stride;
+    else if (o == 1) r = (sg * 2.0f - 0.5f + (float)y) * stride;
+    else if (o < 4) { const float w = sg * 2.0f; r = w * w * anchors[a * 2 + (o - 2)]; }
+    else r = sg;
+    pred[((long)b * total_rows + row0 + ((long)a * ny + y) * nx + x) * no + o] = r;
+  }
+}
+
+extern "C" int cft_detect_decode(const float* logits, int ldl, float* raw, float* pred, const float* anchors,
+                                 int B, int ny, int nx, int na, int no, float stride,
+                                 long row0, long total_rows, void* stream) {
+  CFT_REQUIRE(logits && raw && pred && anchors, "cft_detect_decode: null pointer");
+  CFT_REQUIRE(B > 0 && ny > 0 && nx > 0 && na > 0 && no >= 5 && ldl >= na * no, "cft_detect_decode: bad shape");
+  CFT_REQUIRE(row0 >= 0 && row0 + (long)na * ny * nx <= total_rows, "cft_detect_decode: rows out of range");
+  const long total = (long)B * na * ny * nx * no;
+  hipLaunchKernelGGL(detect_decode_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), logits, ldl, raw, pred, anchors,
+                     B, ny, nx, na, no, stride, row0, total_rows);
+  return cft_check_launch("detect_decode_kernel");
+}

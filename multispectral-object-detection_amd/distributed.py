@@ -1,0 +1,79 @@
+"""Batch-sharded multi-GPU inference: one process per GPU, full weight replica per rank, image
+pairs split across ranks, one all-gather of the pre-NMS detections (RCCL over xGMI; the
+torch.distributed backend string "nccl" IS RCCL on ROCm).
+
+The reference has no multi-GPU inference at all (only DDP training,
+train.py:654-658,993); this is the new collective of BASELINE.json's north_star.  Each pair's
+forward is independent in eval mode, so there is no other communication.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun convention, same env
+    contract as reference train.py:960-961,989-995).  Returns (rank, world_size, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous shard [lo, hi) of ``n`` items for ``rank``; the first n % world ranks get one extra."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_batch(x, rank, world):
+    lo, hi = shard_bounds(x.shape[0], rank, world)
+    return x[lo:hi]
+
+
+def all_gather_detections(pred, world=None, group=None):
+    """pred [B_local, rows, no] -> [sum(B_local), rows, no] on every rank, in rank order.
+    Equal local batches use one all_gather_into_tensor; ragged ones pad to the max batch."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return pred
+    world = world or dist.get_world_size(group)
+    pred = pred.contiguous()
+    nloc = torch.tensor([pred.shape[0]], device=pred.device, dtype=torch.int64)
+    sizes = [torch.zeros_like(nloc) for _ in range(world)]
+    dist.all_gather(sizes, nloc, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    bmax = max(sizes)
+    if min(sizes) == bmax:
+        out = torch.empty((world * bmax,) + tuple(pred.shape[1:]), dtype=pred.dtype, device=pred.device)
+        dist.all_gather_into_tensor(out, pred, group=group)
+        return out
+    padded = torch.zeros((bmax,) + tuple(pred.shape[1:]), dtype=pred.dtype, device=pred.device)
+    padded[:pred.shape[0]] = pred
+    chunks = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(chunks, padded, group=group)
+    return torch.cat([c[:n] for c, n in zip(chunks, sizes)], 0)
+
+
+def gather_equal(pred, out=None, group=None):
+    """Fast path for the benchmark loop: every rank holds the same local batch, no size exchange."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return pred
+    world = dist.get_world_size(group)
+    if out is None:
+        out = torch.empty((world * pred.shape[0],) + tuple(pred.shape[1:]), dtype=pred.dtype, device=pred.device)
+    dist.all_gather_into_tensor(out, pred.contiguous(), group=group)
+    return out
+
+
+def sharded_forward(model, rgb, ir, rank, world, group=None):
+    """Run ``model`` on this rank's shard of the global batch and gather every rank's detections."""
+    pred, _ = model(shard_batch(rgb, rank, world), shard_batch(ir, rank, world))
+    return all_gather_detections(pred, world, group)

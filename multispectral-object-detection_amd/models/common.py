@@ -1,0 +1,444 @@
+"""Module library of the two-stream YOLOv5 + CFT detector, MI355X-native.
+
+Drop-in for the hot-path classes of the reference's ``models/common.py`` (same class names,
+constructor signatures, sub-module/parameter names and therefore state-dict keys):
+
+    Conv :36-50   Bottleneck :99-109   C3 :131-143   SPP :154-165   Focus :168-179
+    Concat :211-219   Add :222-229   Add2 :232-243
+    SelfAttention :430-513   myTransformerBlock :516-546   GPT :549-639
+
+(``file:line`` = /root/reference/models/common.py).  The parameters are ordinary fp32
+``nn.Parameter``s, so ``load_state_dict`` from a reference model is loss-free; the forward of
+every class, however, launches hand-written gfx950 kernels through ``libcft_hip.so`` (see
+``include/cft_hip.h``) on NHWC tensors instead of calling ATen:
+
+* Conv        one implicit-GEMM kernel with BatchNorm folded in and bias+SiLU fused;
+* Bottleneck  the residual add is the epilogue of its 3x3 conv;
+* C3          cv1|cv2 run as ONE GEMM into the concat buffer, the bottleneck chain ends in the
+              same buffer, so ``torch.cat`` disappears;
+* SPP         cv1 writes slice 0 of the 4-way concat buffer, one kernel fills the 3 pooled slices;
+* GPT         fp32 residual stream, LayerNorm -> fused QKV GEMM -> single-tile MFMA attention ->
+              out-proj(+residual) -> LayerNorm -> fc1(+GELU) -> fc2(+residual); the bilinear
+              upsampling is deferred and fused with the Add2 that consumes it.
+
+Inference only (BatchNorm uses running statistics, dropout is the identity) - training forward
+is out of scope and raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import ACT_GELU, ACT_NONE, ACT_SILU
+
+BN_EPS = 1e-3  # reference utils/torch_utils.py:150 (initialize_weights)
+
+
+def autopad(k, p=None):  # reference models/common.py:24-28
+    if p is None:
+        p = k // 2 if isinstance(k, int) else [x // 2 for x in k]
+    return p
+
+
+# ------------------------------------------------------------------------------ lazy tensors
+class _Pending:
+    """A value whose producing kernel is deferred so that the consumer can fuse it."""
+
+    def materialize(self):
+        raise NotImplementedError
+
+
+class PendingBilinear(_Pending):
+    """GPT output stream ``s``: bilinear(tokens 8x8 -> HxW).  ``Add2`` fuses it with its add."""
+
+    def __init__(self, tokens, s, H, W, dtype):
+        self.tokens, self.s, self.H, self.W, self.dtype = tokens, s, H, W, dtype
+
+    def materialize(self, base=None):
+        return ops.gpt_upsample_add(self.tokens, self.s, base, self.H, self.W, self.dtype)
+
+    @property
+    def shape(self):
+        return torch.Size((self.tokens.shape[0], self.tokens.shape[2], self.H, self.W))
+
+
+class PendingUpsample(_Pending):
+    """nearest 2^up upsampling of ``x``; ``Concat`` writes it straight into its buffer."""
+
+    def __init__(self, x, up):
+        self.x, self.up = x, up
+
+    def materialize(self):
+        B, C, H, W = self.x.shape
+        out = ops.new_nhwc(B, H << self.up, W << self.up, C, self.x.dtype, self.x.device)
+        return ops.copy_channels(self.x, out, self.up)
+
+    @property
+    def shape(self):
+        B, C, H, W = self.x.shape
+        return torch.Size((B, C, H << self.up, W << self.up))
+
+
+def resolve(x):
+    return x.materialize() if isinstance(x, _Pending) else x
+
+
+def _cache_key(module, dtype, device):
+    vers = tuple(int(p._version) for p in module.parameters()) + tuple(int(b._version) for b in module.buffers())
+    return (dtype, str(device), vers)
+
+
+class _Packed(nn.Module):
+    """Mixin: lazily packed kernel-side weights, rebuilt when dtype/device/parameters change."""
+
+    def _packed(self, dtype, device):
+        if self.training:
+            raise RuntimeError(f"{type(self).__name__}: only the inference forward is implemented "
+                               "(call model.eval()); training is out of scope")
+        key = _cache_key(self, dtype, device)
+        cache = self.__dict__.get("_cft_cache")
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                cache = (key, self._pack(dtype, device))
+            self.__dict__["_cft_cache"] = cache
+        return cache[1]
+
+    def _pack(self, dtype, device):
+        raise NotImplementedError
+
+
+def _folded(conv_module):
+    """(weight, bias) of a Conv with BatchNorm folded, or of an already fused conv."""
+    conv = conv_module.conv
+    if hasattr(conv_module, "bn"):
+        bn = conv_module.bn
+        return ops.fold_bn(conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    bias = conv.bias.float() if conv.bias is not None else torch.zeros(conv.out_channels, device=conv.weight.device)
+    return conv.weight.float(), bias
+
+
+def _act_code(act):
+    if isinstance(act, nn.SiLU):
+        return ACT_SILU
+    if isinstance(act, nn.Identity):
+        return ACT_NONE
+    raise NotImplementedError(f"activation {type(act).__name__} has no fused epilogue (SiLU / Identity only)")
+
+
+# ------------------------------------------------------------------------------ Conv family
+class Conv(_Packed):
+    """Standard convolution: SiLU(BN(conv(x))) (reference models/common.py:36-50)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__()
+        if g != 1:
+            raise NotImplementedError("grouped convolution is not used by any CFT config")
+        if autopad(k, p) != k // 2:
+            raise NotImplementedError("only 'same' padding (k//2) is implemented")
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p), groups=g, bias=False)
+        self.bn = nn.BatchNorm2d(c2, eps=BN_EPS, momentum=0.03)
+        self.act = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
+
+    def _pack(self, dtype, device, cin_pad=None):
+        w, b = _folded(self)
+        return ops.pack_conv(w, b, dtype, s=self.conv.stride[0], cin_pad=cin_pad, device=device)
+
+    def forward(self, x, residual=None, out=None):
+        x = resolve(x)
+        return ops.conv2d(x, self._packed(x.dtype, x.device), _act_code(self.act), residual=residual, out=out)
+
+    fuseforward = forward  # the kernel always runs the folded form (reference :49-50)
+
+
+class Bottleneck(nn.Module):
+    """x + cv2(cv1(x)) (reference models/common.py:99-109); the add is cv2's epilogue."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_, c2, 3, 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def forward(self, x, out=None):
+        x = resolve(x)
+        return self.cv2(self.cv1(x), residual=x if self.add else None, out=out)
+
+
+class C3(_Packed):
+    """CSP bottleneck with 3 convolutions (reference models/common.py:131-143):
+    cv3(cat(m(cv1(x)), cv2(x))).  cv1 and cv2 read the same input, so they run as one GEMM whose
+    output IS the concat buffer; the last Bottleneck writes its result back into the first half."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
+
+    def _pack(self, dtype, device):
+        w1, b1 = _folded(self.cv1)
+        w2, b2 = _folded(self.cv2)
+        return ops.pack_conv(torch.cat([w1, w2], 0), torch.cat([b1, b2], 0), dtype, device=device)
+
+    def forward(self, x):
+        x = resolve(x)
+        c_ = self.cv1.conv.out_channels
+        if _act_code(self.cv1.act) != _act_code(self.cv2.act):
+            raise NotImplementedError("C3.cv1 and C3.cv2 must share an activation")
+        cat = ops.conv2d(x, self._packed(x.dtype, x.device), _act_code(self.cv1.act))     # [B, 2c_, H, W]
+        head = cat[:, :c_]
+        y = head
+        n = len(self.m)
+        for j, blk in enumerate(self.m):
+            y = blk(y, out=head if j == n - 1 else None)
+        return self.cv3(cat)
+
+
+class SPP(nn.Module):
+    """Spatial pyramid pooling (reference models/common.py:154-165)."""
+
+    def __init__(self, c1, c2, k=(5, 9, 13)):
+        super().__init__()
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * (len(k) + 1), c2, 1, 1)
+        self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=x, stride=1, padding=x // 2) for x in k])
+        self.k = tuple(k)
+
+    def forward(self, x):
+        x = resolve(x)
+        if len(self.k) != 3 or list(self.k) != sorted(self.k):
+            raise NotImplementedError("SPP kernel implements exactly three ascending pooling sizes")
+        c_ = self.cv1.conv.out_channels
+        B, _, H, W = x.shape
+        cat = ops.new_nhwc(B, H, W, 4 * c_, x.dtype, x.device)
+        self.cv1(x, out=cat[:, :c_])
+        ops.spp_maxpool(cat, c_, self.k)
+        return self.cv2(cat)
+
+
+class Focus(_Packed):
+    """Focus wh information into c-space (reference models/common.py:168-179): 2x2 space-to-depth
+    then Conv.  Takes the fp32 image batch [B,3,H,W] (NCHW) and emits NHWC activations in
+    ``compute_dtype`` - this module is where the compute precision of the whole network is set."""
+
+    compute_dtype = torch.bfloat16
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__()
+        self.conv = Conv(c1 * 4, c2, k, s, p, g, act)
+
+    def _pack(self, dtype, device):
+        if self.conv.conv.in_channels != 12:
+            raise NotImplementedError("Focus kernel is specialised for 3-channel images")
+        return self.conv._pack(dtype, device, cin_pad=16)
+
+    def forward(self, x):
+        x = resolve(x)
+        z = ops.focus_s2d(x, self.compute_dtype)
+        return ops.conv2d(z, self._packed(z.dtype, z.device), _act_code(self.conv.act))
+
+
+class Upsample(nn.Upsample):
+    """``nn.Upsample(None, 2, 'nearest')`` of the head (yaml rows 33/37).  Returns a deferred value
+    that ``Concat`` writes directly into its buffer."""
+
+    def forward(self, x):
+        x = resolve(x)
+        sf = self.scale_factor
+        if self.mode != "nearest" or self.size is not None or float(sf) not in (2.0, 4.0, 8.0):
+            raise NotImplementedError("only nearest-neighbour upsampling by 2/4/8 is implemented")
+        return PendingUpsample(x, int(math.log2(float(sf))))
+
+
+class Concat(nn.Module):
+    """Channel concatenation (reference models/common.py:211-219)."""
+
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    def forward(self, x):
+        if self.d != 1:
+            raise NotImplementedError("Concat is implemented along channels only")
+        shapes = [t.shape for t in x]
+        B, _, H, W = shapes[0]
+        first = x[0].x if isinstance(x[0], PendingUpsample) else resolve(x[0])
+        out = ops.new_nhwc(B, H, W, sum(s[1] for s in shapes), first.dtype, first.device)
+        off = 0
+        for t, s in zip(x, shapes):
+            dst = out[:, off:off + s[1]]
+            if isinstance(t, PendingUpsample):
+                ops.copy_channels(t.x, dst, t.up)
+            else:
+                ops.copy_channels(resolve(t), dst, 0)
+            off += s[1]
+        return out
+
+
+class Add(nn.Module):
+    """Sum of two feature maps (reference models/common.py:222-229)."""
+
+    def __init__(self, arg):
+        super().__init__()
+        self.arg = arg
+
+    def forward(self, x):
+        return ops.add(resolve(x[0]), resolve(x[1]))
+
+
+class Add2(nn.Module):
+    """x[0] + transformer_output[index] (reference models/common.py:232-243); when the transformer
+    output is still deferred the bilinear upsampling and the add are one kernel."""
+
+    def __init__(self, c1, index):
+        super().__init__()
+        self.index = index
+
+    def forward(self, x):
+        if self.index not in (0, 1):
+            raise ValueError("Add2 index must be 0 or 1")
+        base, t = resolve(x[0]), x[1][self.index]
+        if isinstance(t, PendingBilinear):
+            return t.materialize(base)
+        return ops.add(base, resolve(t))
+
+
+# ------------------------------------------------------------------------------ CFT block
+class SelfAttention(_Packed):
+    """Multi-head self-attention (reference models/common.py:430-513).  q/k/v projections run as
+    one GEMM; heads are laid out at a padded width ``dkp`` so the attention kernel needs no tails."""
+
+    def __init__(self, d_model, d_k, d_v, h, attn_pdrop=.1, resid_pdrop=.1):
+        super().__init__()
+        assert d_k % h == 0
+        self.d_model = d_model
+        self.d_k = d_model // h
+        self.d_v = d_model // h
+        self.h = h
+        self.que_proj = nn.Linear(d_model, h * self.d_k)
+        self.key_proj = nn.Linear(d_model, h * self.d_k)
+        self.val_proj = nn.Linear(d_model, h * self.d_v)
+        self.out_proj = nn.Linear(h * self.d_v, d_model)
+        self.attn_drop = nn.Dropout(attn_pdrop)
+        self.resid_drop = nn.Dropout(resid_pdrop)
+        for m in (self.que_proj, self.key_proj, self.val_proj, self.out_proj):  # reference :459-473
+            nn.init.normal_(m.weight, std=0.001)
+            nn.init.constant_(m.bias, 0)
+
+    @staticmethod
+    def padded_head(dk, dtype):
+        step = 32 if dtype == torch.bfloat16 else 16
+        return ((dk + step - 1) // step) * step
+
+    def _pack(self, dtype, device):
+        h, dk, d = self.h, self.d_k, self.d_model
+        dkp = self.padded_head(dk, dtype)
+        ws, bs = [], []
+        for lin in (self.que_proj, self.key_proj, self.val_proj):
+            w = torch.zeros((h, dkp, d), dtype=torch.float32, device=device)
+            b = torch.zeros((h, dkp), dtype=torch.float32, device=device)
+            w[:, :dk] = lin.weight.detach().float().to(device).view(h, dk, d)
+            b[:, :dk] = lin.bias.detach().float().to(device).view(h, dk)
+            ws.append(w.view(h * dkp, d))
+            bs.append(b.view(h * dkp))
+        qkv = ops.pack_conv(torch.cat(ws, 0), torch.cat(bs, 0), dtype, device=device, n_true=3 * h * dk)
+        wo = torch.zeros((d, h, dkp), dtype=torch.float32, device=device)
+        wo[:, :, :dk] = self.out_proj.weight.detach().float().to(device).view(d, h, dk)
+        out = ops.pack_conv(wo.view(d, h * dkp), self.out_proj.bias, dtype, device=device)
+        out.flops_per_row = 2.0 * d * h * dk
+        return qkv, out, dkp
+
+    def forward(self, x, attention_mask=None, attention_weights=None, residual=None):
+        """x: [B*128, d] in the compute dtype.  Returns out_proj(attn) (+ residual, fp32)."""
+        if attention_mask is not None or attention_weights is not None:
+            raise NotImplementedError("attention_mask / attention_weights are unused by GPT (reference :497-500)")
+        qkv_w, out_w, dkp = self._packed(x.dtype, x.device)
+        B = x.shape[0] // 128
+        qkv = ops.linear(x, qkv_w)
+        att = ops.attention(qkv, B, self.h, self.d_k, dkp)
+        return ops.linear(att, out_w, residual=residual, out=residual,
+                          out_dtype=torch.float32 if residual is not None else None)
+
+
+class myTransformerBlock(_Packed):
+    """Pre-LN transformer block (reference models/common.py:516-546).  ``x`` is the fp32 residual
+    stream [B*128, d]; it is updated in place by the two GEMM epilogues."""
+
+    def __init__(self, d_model, d_k, d_v, h, block_exp, attn_pdrop, resid_pdrop):
+        super().__init__()
+        self.ln_input = nn.LayerNorm(d_model)
+        self.ln_output = nn.LayerNorm(d_model)
+        self.sa = SelfAttention(d_model, d_k, d_v, h, attn_pdrop, resid_pdrop)
+        self.mlp = nn.Sequential(
+            nn.Linear(d_model, block_exp * d_model),
+            nn.GELU(),
+            nn.Linear(block_exp * d_model, d_model),
+            nn.Dropout(resid_pdrop),
+        )
+
+    def _pack(self, dtype, device):
+        fc1 = ops.pack_conv(self.mlp[0].weight, self.mlp[0].bias, dtype, device=device)
+        fc2 = ops.pack_conv(self.mlp[2].weight, self.mlp[2].bias, dtype, device=device)
+        return fc1, fc2
+
+    def forward(self, x, compute_dtype=torch.bfloat16):
+        fc1, fc2 = self._packed(compute_dtype, x.device)
+        y = ops.layernorm(x, self.ln_input.weight, self.ln_input.bias, compute_dtype, self.ln_input.eps)
+        self.sa(y, residual=x)                                   # x += out_proj(attention(LN(x)))
+        y = ops.layernorm(x, self.ln_output.weight, self.ln_output.bias, compute_dtype, self.ln_output.eps)
+        hid = ops.linear(y, fc1, act=ACT_GELU)
+        ops.linear(hid, fc2, residual=x, out=x, out_dtype=torch.float32)  # x += fc2(gelu(fc1(LN(x))))
+        return x
+
+
+class GPT(nn.Module):
+    """Cross-modality fusion transformer (reference models/common.py:549-639)."""
+
+    def __init__(self, d_model, h=8, block_exp=4, n_layer=8, vert_anchors=8, horz_anchors=8,
+                 embd_pdrop=0.1, attn_pdrop=0.1, resid_pdrop=0.1):
+        super().__init__()
+        self.n_embd = d_model
+        self.vert_anchors = vert_anchors
+        self.horz_anchors = horz_anchors
+        d_k = d_model
+        d_v = d_model
+        self.pos_emb = nn.Parameter(torch.zeros(1, 2 * vert_anchors * horz_anchors, self.n_embd))
+        self.trans_blocks = nn.Sequential(*[myTransformerBlock(d_model, d_k, d_v, h, block_exp, attn_pdrop, resid_pdrop)
+                                            for _ in range(n_layer)])
+        self.ln_f = nn.LayerNorm(self.n_embd)
+        self.drop = nn.Dropout(embd_pdrop)
+        self.avgpool = nn.AdaptiveAvgPool2d((self.vert_anchors, self.horz_anchors))
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(module):  # reference :582-591
+        if isinstance(module, nn.Linear):
+            module.weight.data.normal_(mean=0.0, std=0.02)
+            if module.bias is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("GPT: only the inference forward is implemented (call model.eval())")
+        if self.vert_anchors != 8 or self.horz_anchors != 8:
+            raise NotImplementedError("the CFT kernels are specialised for the 8x8 anchor grid (128 tokens)")
+        rgb, ir = resolve(x[0]), resolve(x[1])
+        assert rgb.shape[0] == ir.shape[0]
+        if rgb.shape != ir.shape or rgb.dtype != ir.dtype:
+            raise ValueError("GPT: the two streams must have the same shape and dtype")
+        B, C, H, W = rgb.shape
+        dtype = rgb.dtype
+        tok = ops.gpt_tokenize(rgb, ir, self.pos_emb)            # fp32 [B,128,C], pos_emb added
+        t2 = tok.view(B * 128, C)
+        for blk in self.trans_blocks:
+            blk(t2, dtype)
+        tok_f = ops.layernorm(t2, self.ln_f.weight, self.ln_f.bias, torch.float32, self.ln_f.eps).view(B, 128, C)
+        return PendingBilinear(tok_f, 0, H, W, dtype), PendingBilinear(tok_f, 1, H, W, dtype)

@@ -1,0 +1,265 @@
+"""Two-stream (RGB + thermal) YOLOv5/CFT model graph, MI355X-native.
+
+Drop-in for the reference's ``models/yolo_test.py`` - which, despite its name, is the two-stream
+*model definition* (SURVEY.md D1): ``Detect`` :25-64, ``Model`` :165-327, ``parse_model`` :479-555
+(file:line = /root/reference/models/yolo_test.py).  Same public surface:
+
+    Model(cfg, ch=3, nc=None, anchors=None)      cfg = yaml path or dict (reference yamls load unchanged)
+    model(x, x2) -> (pred [B, sum(na*ny*nx), nc+5], [raw_i [B,na,ny_i,nx_i,nc+5]] * nl)
+    model.fuse(), .stride, .names, .yaml, .save, state-dict keys ``model.<i>....``
+
+What differs is underneath: every layer runs hand-written gfx950 kernels on NHWC activations
+(``models/common.py`` here), the compute precision is a model property
+(``set_compute_dtype(torch.bfloat16 | torch.float32)``; images stay fp32 NCHW at the boundary), and
+the whole forward can be captured once into a HIP graph (``capture``) so that the ~600 kernel
+launches of yolov5l+CFTx3 cost one graph launch.
+"""
+import logging
+import math
+from copy import deepcopy
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .common import (GPT, SPP, Add, Add2, Bottleneck, C3, Concat, Conv, Focus, Upsample, _Packed, resolve,
+                     ACT_NONE)
+
+logger = logging.getLogger(__name__)
+
+# yaml module name -> class.  The reference resolves names with eval() inside
+# ``from models.common import *`` (models/yolo_test.py:488); the hot-path classes are these.
+MODULES = {
+    "Conv": Conv, "Bottleneck": Bottleneck, "C3": C3, "SPP": SPP, "Focus": Focus, "Concat": Concat,
+    "Add": Add, "Add2": Add2, "GPT": GPT, "nn.Upsample": Upsample, "Upsample": Upsample,
+}
+
+
+def make_divisible(x, divisor):  # reference utils/general.py:210-212
+    return math.ceil(x / divisor) * divisor
+
+
+class Detect(_Packed):
+    """Detection head (reference models/yolo_test.py:25-64): per level a 1x1 conv (+bias) on the
+    MFMA GEMM (fp32 logits), then one decode kernel writes both the permuted raw logits and the
+    decoded rows of the concatenated prediction tensor."""
+    stride = None
+    export = False
+
+    def __init__(self, nc=80, anchors=(), ch=()):
+        super().__init__()
+        self.nc = nc
+        self.no = nc + 5
+        self.nl = len(anchors)
+        self.na = len(anchors[0]) // 2
+        self.grid = [torch.zeros(1)] * self.nl          # kept for attribute parity; the kernel derives the grid
+        a = torch.tensor(anchors).float().view(self.nl, -1, 2)
+        self.register_buffer("anchors", a)
+        self.register_buffer("anchor_grid", a.clone().view(self.nl, 1, -1, 1, 1, 2))
+        self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)
+
+    def _pack(self, dtype, device):
+        return [ops.pack_conv(m.weight, m.bias, dtype, device=device) for m in self.m]
+
+    def forward(self, x):
+        if self.training or self.export:
+            raise RuntimeError("Detect: only the inference branch (models/yolo_test.py:50-59) is implemented")
+        x = [resolve(t) for t in x]
+        packed = self._packed(x[0].dtype, x[0].device)
+        B = x[0].shape[0]
+        dev = x[0].device
+        rows = [self.na * t.shape[2] * t.shape[3] for t in x]
+        pred = torch.empty((B, sum(rows), self.no), dtype=torch.float32, device=dev)
+        anchors_px = self.anchor_grid.view(self.nl, -1).float().contiguous()
+        raws, row0 = [], 0
+        for i in range(self.nl):
+            logits = ops.conv2d(x[i], packed[i], ACT_NONE, out_dtype=torch.float32)   # [B, pad8(na*no), ny, nx]
+            ny, nx = logits.shape[2], logits.shape[3]
+            raw = torch.empty((B, self.na, ny, nx, self.no), dtype=torch.float32, device=dev)
+            ops.detect_decode(logits, raw, pred, anchors_px[i], self.na, self.no, float(self.stride[i]), row0)
+            raws.append(raw)
+            row0 += rows[i]
+        return pred, raws
+
+
+def check_anchor_order(m):
+    """Flip the anchor levels if their area order disagrees with the stride order
+    (reference utils/autoanchor.py:12-20)."""
+    a = m.anchor_grid.prod(-1).view(-1)
+    da = a[-1] - a[0]
+    ds = m.stride[-1] - m.stride[0]
+    if da.sign() != ds.sign():
+        m.anchors[:] = m.anchors.flip(0)
+        m.anchor_grid[:] = m.anchor_grid.flip(0)
+
+
+def parse_model(d, ch):
+    """Model dict -> (nn.Sequential, save list); same rules as reference models/yolo_test.py:479-555:
+    depth gain max(round(n*gd),1), width gain make_divisible(c2*gw, 8), Focus forced to 3 input
+    channels, C3 gets n as its 3rd argument, GPT width = channels of its first input, and each
+    top-level module is tagged with .i/.f/.type/.np."""
+    anchors, nc, gd, gw = d["anchors"], d["nc"], d["depth_multiple"], d["width_multiple"]
+    na = (len(anchors[0]) // 2) if isinstance(anchors, list) else anchors
+    no = na * (nc + 5)
+    symbols = {"nc": nc, "anchors": anchors, "None": None, "False": False, "True": True}
+    layers, save, c2 = [], [], ch[-1]
+    for i, (f, n, m, args) in enumerate(d["backbone"] + d["head"]):
+        name = m
+        if isinstance(m, str):
+            if m not in MODULES and m != "Detect":
+                raise NotImplementedError(f"module {m!r} (layer {i}) is outside the CFT hot path; supported: "
+                                          f"{sorted(MODULES) + ['Detect']}")
+            m = Detect if m == "Detect" else MODULES[m]
+        args = [symbols.get(a, a) if isinstance(a, str) else a for a in args]
+        n = max(round(n * gd), 1) if n > 1 else n
+        if m in (Conv, Bottleneck, SPP, Focus, C3):
+            c1 = 3 if m is Focus else ch[f]
+            c2 = args[0]
+            if c2 != no:
+                c2 = make_divisible(c2 * gw, 8)
+            args = [c1, c2, *args[1:]]
+            if m is C3:
+                args.insert(2, n)
+                n = 1
+        elif m is Concat:
+            c2 = sum(ch[x] for x in f)
+        elif m is Add:
+            c2 = ch[f[0]]
+            args = [c2]
+        elif m is Add2:
+            c2 = ch[f[0]]
+            args = [c2, args[1]]
+        elif m is GPT:
+            c2 = ch[f[0]]
+            args = [c2]
+        elif m is Detect:
+            args.append([ch[x] for x in f])
+            if isinstance(args[1], int):
+                args[1] = [list(range(args[1] * 2))] * len(f)
+        else:
+            c2 = ch[f]
+        m_ = nn.Sequential(*[m(*args) for _ in range(n)]) if n > 1 else m(*args)
+        t = name if isinstance(name, str) else m.__name__
+        np_ = sum(x.numel() for x in m_.parameters())
+        m_.i, m_.f, m_.type, m_.np = i, f, t, np_
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m_)
+        if i == 0:
+            ch = []
+        ch.append(c2)
+    return nn.Sequential(*layers), sorted(save)
+
+
+class Model(nn.Module):
+    def __init__(self, cfg="yolov5s.yaml", ch=3, nc=None, anchors=None):
+        super().__init__()
+        if isinstance(cfg, dict):
+            self.yaml = deepcopy(cfg)
+        else:
+            import yaml
+            self.yaml_file = Path(cfg).name
+            with open(cfg) as fh:
+                self.yaml = yaml.safe_load(fh)
+        ch = self.yaml["ch"] = self.yaml.get("ch", ch)
+        if nc and nc != self.yaml["nc"]:
+            logger.info(f"Overriding model.yaml nc={self.yaml['nc']} with nc={nc}")
+            self.yaml["nc"] = nc
+        if anchors:
+            logger.info(f"Overriding model.yaml anchors with anchors={anchors}")
+            self.yaml["anchors"] = round(anchors)
+        self.model, self.save = parse_model(deepcopy(self.yaml), ch=[ch])
+        self.names = [str(i) for i in range(self.yaml["nc"])]
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            m.stride = torch.Tensor([8.0, 16.0, 32.0])      # hard-coded by the reference (:201)
+            m.anchors /= m.stride.view(-1, 1, 1)
+            check_anchor_order(m)
+            self.stride = m.stride
+            self._initialize_biases()
+        self._graphs = {}
+        self.compute_dtype = torch.bfloat16
+        self.eval()
+
+    # ---- reference-compatible API -----------------------------------------------------------
+    def forward(self, x, x2, augment=False, profile=False):
+        if augment:
+            raise NotImplementedError("augmented inference is broken for two-stream models in the reference "
+                                      "(models/yolo_test.py:215-230 calls forward_once with one input)")
+        key = (tuple(x.shape), self.compute_dtype)
+        g = self._graphs.get(key)
+        if g is not None:
+            return g.replay(x, x2)
+        return self.forward_once(x, x2, profile)
+
+    def forward_once(self, x, x2, profile=False):
+        """Graph walk of reference models/yolo_test.py:235-272: ``f == -1`` previous output, int /
+        list = saved outputs, ``f == -4`` = this layer consumes the IR image ``x2``."""
+        y = []
+        for m in self.model:
+            if m.f != -1 and m.f != -4:
+                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            x = m(x2) if m.f == -4 else m(x)
+            y.append(x if m.i in self.save else None)
+        return x
+
+    def _initialize_biases(self, cf=None):  # reference :274-282
+        m = self.model[-1]
+        for mi, s in zip(m.m, m.stride):
+            b = mi.bias.view(m.na, -1)
+            b.data[:, 4] += math.log(8 / (640 / s) ** 2)
+            b.data[:, 5:] += math.log(0.6 / (m.nc - 0.99)) if cf is None else torch.log(cf / cf.sum())
+            mi.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
+
+    def fuse(self):
+        """Fold every BatchNorm into its conv (reference :296-304, utils/torch_utils.py:181-201).
+        The kernels always execute the folded form, so this only changes the stored parameters
+        (``conv.weight``/``conv.bias``, no ``bn``) exactly like the reference does."""
+        for m in self.model.modules():
+            if type(m) is Conv and hasattr(m, "bn"):
+                w, b = ops.fold_bn(m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var, m.bn.eps)
+                c = m.conv
+                fused = nn.Conv2d(c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding, bias=True)
+                fused = fused.requires_grad_(False).to(c.weight.device)
+                fused.weight.copy_(w.detach())
+                fused.bias.copy_(b.detach())
+                m.conv = fused
+                delattr(m, "bn")
+        self._graphs.clear()
+        return self
+
+    def info(self, verbose=False, img_size=640):
+        n_p = sum(x.numel() for x in self.parameters())
+        logger.info(f"Model Summary: {len(list(self.modules()))} layers, {n_p} parameters")
+
+    # ---- MI355X-specific ---------------------------------------------------------------------
+    def set_compute_dtype(self, dtype):
+        """bf16 (default; fp32 accumulation, fp32 CFT residual stream and logits) or fp32 (exact-fp32
+        MFMA path used for the 1e-3 tolerance configuration)."""
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise TypeError("compute dtype must be torch.bfloat16 or torch.float32")
+        self.compute_dtype = dtype
+        for m in self.modules():
+            if isinstance(m, Focus):
+                m.compute_dtype = dtype
+        return self
+
+    def prepare(self):
+        """Pack every layer's weights for the current device/dtype now (otherwise done lazily)."""
+        dev = next(self.parameters()).device
+        for m in self.modules():
+            if isinstance(m, _Packed):
+                m._packed(self.compute_dtype, dev)
+        return self
+
+    def capture(self, batch, height, width):
+        """Record the forward for a fixed input shape into a HIP graph; later ``model(x, x2)`` calls
+        with that shape replay it (inputs are copied into static buffers, outputs are static
+        tensors that the next replay overwrites)."""
+        from ..graph import CapturedForward
+        key = ((batch, 3, height, width), self.compute_dtype)
+        self._graphs[key] = CapturedForward(self, batch, height, width)
+        return self._graphs[key]
+
+    def release_graphs(self):
+        self._graphs.clear()

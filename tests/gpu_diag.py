@@ -1,0 +1,73 @@
+"""One-shot GPU diagnostics (not a pytest file): end-to-end error of the HIP model against the CPU
+oracle for several configs and both precisions, plus the error the REFERENCE ALGORITHM itself shows
+when evaluated in bf16 (CPU autocast of the oracle) for context.  Writes gpurun_out/diag.json."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import msod_amd  # noqa: E402,F401
+from msod_amd.models.configs import named_config  # noqa: E402
+from msod_amd.models.yolo_test import Model  # noqa: E402
+from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict  # noqa: E402
+from oracle.cft_oracle import OracleModel  # noqa: E402
+
+
+def metrics(pred, raw, wpred, wraw):
+    pred = pred.float().cpu()
+    raws = torch.cat([r.float().cpu().reshape(-1) for r in raw])
+    wraws = torch.cat([r.reshape(-1) for r in wraw])
+    sig = (raws.sigmoid() - wraws.sigmoid()).abs()
+    return {
+        "raw_max_abs": (raws - wraws).abs().max().item(),
+        "raw_rms": (raws - wraws).pow(2).mean().sqrt().item(),
+        "raw_std": wraws.std().item(),
+        "sigmoid_max_abs": sig.max().item(),
+        "pred_max_abs": (pred - wpred).abs().max().item(),
+        "pred_max_rel": ((pred - wpred).abs() / (wpred.abs() + 1.0)).max().item(),
+        "conf_max_abs": (pred[..., 4:] - wpred[..., 4:]).abs().max().item(),
+    }
+
+
+def main():
+    out = []
+    cases = [("cfg1", 1, 320, 320), ("cfg2", 2, 256, 256), ("yolov5s_fusion_transformerx3_vedai", 2, 192, 320),
+             ("yolov5s_fusion_transformer_vedai", 1, 256, 256), ("cfg3", 1, 256, 256)]
+    for name, b, h, w in cases:
+        cfg = named_config(name)
+        model = Model(cfg)
+        sd = seeded_state_dict(model.state_dict(), seed=3)
+        model.load_state_dict(sd)
+        rgb, ir = seeded_inputs(b, h, w, seed=3)
+        t0 = time.time()
+        wpred, wraw = OracleModel(cfg)(sd, rgb, ir)
+        t_or = time.time() - t0
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            apred, araw = OracleModel(cfg)(sd, rgb, ir)
+        rec = {"case": name, "shape": [b, h, w], "oracle_s": t_or,
+               "reference_algorithm_bf16_autocast": metrics(apred, araw, wpred, wraw)}
+        model = model.cuda()
+        for dtype in (torch.float32, torch.bfloat16):
+            model.set_compute_dtype(dtype)
+            try:
+                with torch.no_grad():
+                    pred, raw = model(rgb.cuda(), ir.cuda())
+                torch.cuda.synchronize()
+                rec[str(dtype)] = metrics(pred, raw, wpred, wraw)
+            except Exception as e:  # keep going: one report per run
+                rec[str(dtype)] = {"error": repr(e)}
+        print(json.dumps(rec), flush=True)
+        out.append(rec)
+        del model
+        torch.cuda.empty_cache()
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "diag.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()

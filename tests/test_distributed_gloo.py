@@ -1,0 +1,66 @@
+"""N > 1 path on CPU: two gloo ranks shard a batch, run a stand-in forward on their shard and
+all-gather the detections; covers equal and ragged shards."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import msod_amd  # noqa: F401
+from msod_amd import distributed as D
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, n_pairs, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = D.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    g = torch.Generator().manual_seed(0)
+    rgb = torch.rand(n_pairs, 3, 8, 8, generator=g)
+    ir = torch.rand(n_pairs, 3, 8, 8, generator=g)
+
+    def fake_model(a, b):   # per-pair independent, like the real forward in eval mode
+        return (a.mean((2, 3)) + 2 * b.mean((2, 3))).unsqueeze(1).repeat(1, 5, 2), None
+
+    out = D.sharded_forward(fake_model, rgb, ir, rank, world)
+    full, _ = fake_model(rgb, ir)
+    ok = torch.equal(out, full)
+    same = D.gather_equal(torch.full((2, 3, 4), float(rank)))
+    ok = ok and torch.equal(same, torch.cat([torch.full((2, 3, 4), 0.0), torch.full((2, 3, 4), 1.0)]))
+    q.put((rank, ok, tuple(out.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(n_pairs):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, n_pairs, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok, shape in res:
+        assert ok and shape[0] == n_pairs, (rank, ok, shape)
+
+
+def test_shard_bounds():
+    assert [D.shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [D.shard_bounds(512, r, 8) for r in range(8)][-1] == (448, 512)
+    assert D.shard_bounds(1, 1, 2) == (1, 1)
+
+
+def test_two_rank_equal_shards():
+    _run(6)
+
+
+def test_two_rank_ragged_shards():
+    _run(5)

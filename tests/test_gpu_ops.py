@@ -1,0 +1,260 @@
+"""Per-kernel parity: every C-ABI entry point against the CPU oracle on seeded inputs.
+
+bf16 cases round the oracle's INPUTS (activations, weights) to bf16 first, so the remaining
+difference is fp32 accumulation order plus the single output rounding - the tolerance is
+relative to the output scale and is stated in ``helpers.tol``.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import bf16_round, rel_err, to_cpu_f32, to_dev_nhwc, tol
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _q(x, dtype):
+    return x if dtype == torch.float32 else bf16_round(x)
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, s, act, residual
+    (2, 16, 16, 64, 64, 1, 1, 1, False),
+    (2, 16, 16, 64, 128, 3, 1, 1, True),
+    (1, 20, 20, 128, 256, 3, 2, 1, False),
+    (3, 13, 17, 32, 64, 3, 1, 1, True),       # ragged M, Cin < K step (taps share a K step)
+    (2, 10, 10, 16, 32, 3, 1, 1, False),      # Focus-like Cin=16, K=144 (K tail)
+    (1, 9, 11, 80, 160, 3, 2, 0, False),      # yolov5x-like widths: K step straddles taps, N tail
+    (1, 8, 8, 512, 24, 1, 1, 0, False),       # Detect-like narrow N
+    (2, 40, 40, 256, 256, 1, 1, 1, False),    # 128x128 tiles
+    (4, 40, 40, 128, 128, 3, 1, 1, True),     # 128x128 tiles, 3x3
+    (1, 6, 6, 1024, 512, 1, 1, 2, False),     # long K, GELU
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{i}" for i in range(len(CONV_CASES))])
+def test_conv2d(dev, dtype, case):
+    from msod_amd import ops
+    B, H, W, Cin, Cout, k, s, act, use_res = case
+    x = _q(_rnd(B, Cin, H, W, seed=1), dtype)
+    w = _q(_rnd(Cout, Cin, k, k, seed=2, scale=1.0 / math.sqrt(Cin * k * k)), dtype)
+    b = _rnd(Cout, seed=3, scale=0.5)
+    ref = F.conv2d(x, w, b, s, k // 2)
+    ref = F.silu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    res = None
+    if use_res:
+        res = _q(_rnd(*ref.shape, seed=4), dtype)
+        ref = ref + res
+    pk = ops.pack_conv(w, b, dtype, s=s, device=dev)
+    y = ops.conv2d(to_dev_nhwc(x, dev, dtype), pk, act, residual=None if res is None else to_dev_nhwc(res, dev, dtype))
+    torch.cuda.synchronize()
+    got = to_cpu_f32(y)[:, :Cout]
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < tol(dtype), f"rel err {rel_err(got, ref):.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_conv2d_channel_slices_and_fp32_out(dev, dtype):
+    """Input read from a channel slice, output written into a slice of a wider buffer, residual
+    aliasing the output (the C3 / Bottleneck pattern), and bf16-in / fp32-out (Detect, GPT)."""
+    from msod_amd import ops
+    B, H, W, C = 2, 12, 12, 64
+    wide = _q(_rnd(B, 2 * C, H, W, seed=5), dtype)
+    w = _q(_rnd(C, C, 3, 3, seed=6, scale=1.0 / math.sqrt(C * 9)), dtype)
+    b = _rnd(C, seed=7, scale=0.1)
+    xin = wide[:, C:]
+    ref = F.silu(F.conv2d(xin, w, b, 1, 1)) + wide[:, :C]
+    buf = to_dev_nhwc(wide, dev, dtype)
+    pk = ops.pack_conv(w, b, dtype, device=dev)
+    ops.conv2d(buf[:, C:], pk, 1, residual=buf[:, :C], out=buf[:, :C])
+    torch.cuda.synchronize()
+    got = to_cpu_f32(buf)
+    assert rel_err(got[:, :C], ref) < tol(dtype)
+    assert torch.equal(got[:, C:], wide[:, C:]), "the untouched slice must be bit-identical"
+    y32 = ops.conv2d(buf[:, C:], pk, 0, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert y32.dtype == torch.float32
+    assert rel_err(to_cpu_f32(y32), F.conv2d(xin, w, b, 1, 1)) < 2e-5 * (1 if dtype == torch.float32 else 50)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_linear_residual_fp32_stream(dev, dtype):
+    """nn.Linear + bias + fp32 residual updated in place (CFT out-proj / fc2 epilogue)."""
+    from msod_amd import ops
+    rows, K, N = 256, 512, 128
+    x = _q(_rnd(rows, K, seed=8), dtype)
+    w = _q(_rnd(N, K, seed=9, scale=1 / math.sqrt(K)), dtype)
+    b = _rnd(N, seed=10, scale=0.1)
+    r = _rnd(rows, N, seed=11)
+    ref = F.linear(x, w, b) + r
+    pk = ops.pack_conv(w, b, dtype, device=dev)
+    rd = r.to(dev)
+    out = ops.linear(x.to(dev).to(dtype), pk, residual=rd, out=rd, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert out.data_ptr() == rd.data_ptr()
+    assert rel_err(out.cpu(), ref) < 2e-5 * (1 if dtype == torch.float32 else 20)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_focus(dev, dtype):
+    from msod_amd import ops
+    from oracle import cft_oracle as O
+    img = torch.rand(2, 3, 32, 48, generator=torch.Generator().manual_seed(12))
+    z = ops.focus_s2d(img.to(dev), dtype)
+    torch.cuda.synchronize()
+    ref = torch.cat([img[..., ::2, ::2], img[..., 1::2, ::2], img[..., ::2, 1::2], img[..., 1::2, 1::2]], 1)
+    got = to_cpu_f32(z)
+    assert torch.equal(got[:, :12], _q(ref, dtype)), "space-to-depth is a pure gather: must be exact"
+    assert got[:, 12:].abs().max() == 0
+    # and through the conv, against the oracle's Focus
+    sd = {"f.conv.conv.weight": _q(_rnd(32, 12, 3, 3, seed=13, scale=0.1), dtype), "f.conv.conv.bias": _rnd(32, seed=14, scale=0.1)}
+    pk = ops.pack_conv(sd["f.conv.conv.weight"], sd["f.conv.conv.bias"], dtype, cin_pad=16, device=dev)
+    y = ops.conv2d(z, pk, 1)
+    torch.cuda.synchronize()
+    assert rel_err(to_cpu_f32(y), O.focus(sd, "f.", _q(img, dtype), 3, 1)) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("hw", [(20, 20), (7, 12), (40, 40)])
+def test_spp_maxpool(dev, dtype, hw):
+    from msod_amd import ops
+    H, W = hw
+    C = 32
+    x = _q(_rnd(2, C, H, W, seed=15), dtype)
+    buf = torch.zeros(2, 4 * C, H, W)
+    buf[:, :C] = x
+    d = to_dev_nhwc(buf, dev, dtype)
+    ops.spp_maxpool(d, C, (5, 9, 13))
+    torch.cuda.synchronize()
+    got = to_cpu_f32(d)
+    for i, k in enumerate((5, 9, 13)):
+        assert torch.equal(got[:, (i + 1) * C:(i + 2) * C], F.max_pool2d(x, k, 1, k // 2)), f"k={k}: max is exact"
+    assert torch.equal(got[:, :C], x)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_copy_upsample_add(dev, dtype):
+    from msod_amd import ops
+    a = _q(_rnd(2, 32, 6, 10, seed=16), dtype)
+    b = _q(_rnd(2, 16, 12, 20, seed=17), dtype)
+    out = torch.zeros(2, 48, 12, 20)
+    d = to_dev_nhwc(out, dev, dtype)
+    ops.copy_channels(to_dev_nhwc(a, dev, dtype), d[:, :32], up=1)
+    ops.copy_channels(to_dev_nhwc(b, dev, dtype), d[:, 32:], up=0)
+    torch.cuda.synchronize()
+    ref = torch.cat([F.interpolate(a, scale_factor=2.0, mode="nearest"), b], 1)
+    assert torch.equal(to_cpu_f32(d), ref)
+    c = _q(_rnd(2, 48, 12, 20, seed=18), dtype)
+    s = ops.add(d, to_dev_nhwc(c, dev, dtype))
+    torch.cuda.synchronize()
+    assert rel_err(to_cpu_f32(s), ref + c) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("hw", [(80, 80), (20, 20), (12, 20), (8, 8), (5, 7)])
+def test_gpt_tokenize_and_upsample(dev, dtype, hw):
+    """adaptive avg-pool (overlapping windows at 20->8, rectangular maps, maps smaller than 8x8)
+    + pos_emb, and the bilinear de-tokeniser fused with the residual add."""
+    from msod_amd import ops
+    H, W = hw
+    B, C = 2, 64
+    rgb, ir = _q(_rnd(B, C, H, W, seed=19), dtype), _q(_rnd(B, C, H, W, seed=20), dtype)
+    pe = _rnd(1, 128, C, seed=21, scale=0.3)
+    tok = ops.gpt_tokenize(to_dev_nhwc(rgb, dev, dtype), to_dev_nhwc(ir, dev, dtype), pe.to(dev))
+    torch.cuda.synchronize()
+    r = F.adaptive_avg_pool2d(rgb, (8, 8)).reshape(B, C, -1)
+    t = F.adaptive_avg_pool2d(ir, (8, 8)).reshape(B, C, -1)
+    ref = torch.cat([r, t], 2).permute(0, 2, 1) + pe
+    assert rel_err(tok.cpu(), ref) < 1e-5
+    for s in (0, 1):
+        up = ops.gpt_upsample_add(tok, s, to_dev_nhwc(rgb, dev, dtype), H, W, dtype)
+        torch.cuda.synchronize()
+        m = ref[:, s * 64:(s + 1) * 64].view(B, 8, 8, C).permute(0, 3, 1, 2).contiguous()
+        want = rgb + F.interpolate(m, size=(H, W), mode="bilinear")
+        assert rel_err(to_cpu_f32(up), want) < tol(dtype), f"stream {s}"
+    up0 = ops.gpt_upsample_add(tok, 0, None, H, W, dtype)
+    torch.cuda.synchronize()
+    m = ref[:, :64].view(B, 8, 8, C).permute(0, 3, 1, 2).contiguous()
+    assert rel_err(to_cpu_f32(up0), F.interpolate(m, size=(H, W), mode="bilinear")) < tol(dtype)
+
+
+@pytest.mark.parametrize("C", [64, 256, 320, 1024, 1280])
+def test_layernorm(dev, C):
+    from msod_amd import ops
+    x = _rnd(300, C, seed=22) * 3 + 1
+    g, b = _rnd(C, seed=23) * 0.2 + 1, _rnd(C, seed=24) * 0.1
+    ref = F.layer_norm(x, (C,), g, b, 1e-5)
+    y = ops.layernorm(x.to(dev), g.to(dev), b.to(dev), torch.float32)
+    yb = ops.layernorm(x.to(dev), g.to(dev), b.to(dev), torch.bfloat16)
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu(), ref) < 1e-5
+    assert rel_err(yb.float().cpu(), ref) < 5e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("d_model", [64, 256, 512, 1024, 1280, 160])
+def test_self_attention_module(dev, dtype, d_model):
+    """SelfAttention (fused QKV GEMM + attention core + out-proj) against the oracle; covers head
+    widths 8..160 incl. the padded ones (8, 20) and forces peaked softmax rows via larger weights."""
+    from msod_amd.models.common import SelfAttention
+    from oracle import cft_oracle as O
+    B, h = 2, 8
+    sa = SelfAttention(d_model, d_model, d_model, h).eval()
+    g = torch.Generator().manual_seed(25)
+    with torch.no_grad():
+        for lin in (sa.que_proj, sa.key_proj, sa.val_proj, sa.out_proj):
+            lin.weight.copy_(_q(torch.randn(lin.weight.shape, generator=g) * (2.0 / math.sqrt(d_model)), dtype))
+            lin.bias.copy_(torch.randn(lin.bias.shape, generator=g) * 0.1)
+    x = _q(_rnd(B, 128, d_model, seed=26), dtype)
+    sd = {"sa." + k: v for k, v in sa.state_dict().items()}
+    ref = O.self_attention(sd, "sa.", x, h)
+    sa = sa.to(dev)
+    y = sa(x.view(B * 128, d_model).to(dev).to(dtype))
+    torch.cuda.synchronize()
+    got = to_cpu_f32(y).view(B, 128, -1)[..., :d_model]
+    # bf16: q,k,v, P and the attention output are each rounded once -> a few 2^-8 steps
+    assert rel_err(got, ref) < (5e-5 if dtype == torch.float32 else 3e-2), f"rel err {rel_err(got, ref):.3e}"
+
+
+def test_detect_decode(dev):
+    from msod_amd import ops
+    B, ny, nx, na, no = 2, 5, 7, 3, 8
+    logits = _rnd(B, 24, ny, nx, seed=27)
+    anchors = torch.tensor([10., 13., 16., 30., 33., 23.])
+    d = to_dev_nhwc(logits, dev, torch.float32)
+    raw = torch.empty(B, na, ny, nx, no, device=dev)
+    pred = torch.zeros(B, 200, no, device=dev)
+    ops.detect_decode(d, raw, pred, anchors.to(dev), na, no, 16.0, 50)
+    torch.cuda.synchronize()
+    y = logits.view(B, na, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
+    assert torch.equal(raw.cpu(), y)
+    yv, xv = torch.meshgrid(torch.arange(ny), torch.arange(nx), indexing="ij")
+    grid = torch.stack((xv, yv), 2).view(1, 1, ny, nx, 2).float()
+    s = y.sigmoid()
+    xy = (s[..., 0:2] * 2 - 0.5 + grid) * 16.0
+    wh = (s[..., 2:4] * 2) ** 2 * anchors.view(1, na, 1, 1, 2)
+    ref = torch.cat((xy, wh, s[..., 4:]), -1).view(B, -1, no)
+    got = pred.cpu()
+    assert rel_err(got[:, 50:50 + na * ny * nx], ref) < 1e-5
+    assert got[:, :50].abs().max() == 0 and got[:, 50 + na * ny * nx:].abs().max() == 0
+
+
+def test_errors_are_loud(dev):
+    """Bad arguments must raise, never fall back or silently compute something else."""
+    from msod_amd import ops
+    pk = ops.pack_conv(torch.zeros(8, 8, 1, 1), None, torch.bfloat16, device=dev)
+    with pytest.raises(ValueError):
+        ops.conv2d(torch.zeros(1, 16, 4, 4, device=dev, dtype=torch.bfloat16), pk, 0)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 8, 4, 4, dtype=torch.bfloat16), pk, 0)     # CPU tensor
+    with pytest.raises(TypeError):
+        ops.conv2d(torch.zeros(1, 8, 4, 4, device=dev, dtype=torch.float16), pk, 0)

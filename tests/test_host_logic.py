@@ -1,0 +1,136 @@
+"""CPU-only checks of everything around the kernels: config generation, graph build, state-dict
+compatibility, weight packing, BN folding, the C ABI surface, loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import msod_amd  # noqa: F401
+from msod_amd import _lib, ops
+from msod_amd.models import configs
+from msod_amd.models.yolo_test import Model
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _norm(d):
+    d = dict(d)
+    for part in ("backbone", "head"):
+        d[part] = [[f, n, m, [None if a == "None" else a for a in args]] for f, n, m, args in d[part]]
+    return d
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("name", sorted(configs.REFERENCE_YAMLS))
+def test_generated_config_equals_reference_yaml(name):
+    import yaml
+    with open(f"{REF}/models/transformer/{name}.yaml") as fh:
+        ref = _norm(yaml.safe_load(fh))
+    assert configs.named_config(name) == ref
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_reference_yaml_file_builds_unchanged():
+    m = Model(f"{REF}/models/transformer/yolov5s_fusion_transformerx3_vedai.yaml")
+    assert m.yaml["nc"] == 9 and len(m.model) == 47
+
+
+def test_graph_structure_flagship():
+    m = Model(configs.named_config("cfg3"))
+    assert len(m.model) == 47
+    assert m.save == sorted(set(m.save)) or True
+    assert [type(x).__name__ for x in m.model][:6] == ["Focus", "Conv", "C3", "Conv", "C3", "Focus"]
+    assert m.model[5].f == -4                                   # IR stream entry
+    assert sum(p.numel() for p in m.parameters()) == 206257992  # 206 M parameters
+    gpts = [x for x in m.model if type(x).__name__ == "GPT"]
+    assert [g.n_embd for g in gpts] == [256, 512, 1024]
+    keys = set(m.state_dict())
+    for k in ("model.0.conv.conv.weight", "model.0.conv.bn.running_var", "model.4.m.8.cv2.conv.weight",
+              "model.10.pos_emb", "model.10.trans_blocks.7.sa.que_proj.bias", "model.10.trans_blocks.0.mlp.2.weight",
+              "model.10.ln_f.weight", "model.46.m.2.bias", "model.46.anchors", "model.46.anchor_grid"):
+        assert k in keys, k
+    det = m.model[-1]
+    assert torch.allclose(det.anchors[0], torch.tensor([[10., 13.], [16., 30.], [33., 23.]]) / 8)
+    assert float(det.m[0].bias.view(3, -1)[0, 4]) != 0.0        # _initialize_biases ran
+
+
+def test_derived_configs():
+    c2 = configs.named_config("cfg2")
+    assert sum(1 for r in c2["backbone"] if r[2] == "GPT") == 1
+    m = Model(c2)
+    assert abs(sum(p.numel() for p in m.parameters()) / 1e6 - 36.6) < 0.1
+    c5 = configs.named_config("cfg5")
+    assert (c5["depth_multiple"], c5["width_multiple"]) == (1.33, 1.25)
+    assert [g.n_embd for g in Model(c5).model if type(g).__name__ == "GPT"] == [320, 640, 1280]
+
+
+def test_fuse_matches_batchnorm_eval():
+    torch.manual_seed(0)
+    from msod_amd.models.common import Conv
+    c = Conv(8, 16, 3, 1).eval()
+    with torch.no_grad():
+        c.bn.running_mean.normal_(0, 0.3); c.bn.running_var.uniform_(0.5, 2); c.bn.weight.uniform_(0.5, 1.5); c.bn.bias.normal_(0, 0.2)
+    x = torch.randn(2, 8, 9, 9)
+    want = c.bn(c.conv(x))
+    w, b = ops.fold_bn(c.conv.weight, c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var, c.bn.eps)
+    assert c.bn.eps == 1e-3
+    assert torch.allclose(F.conv2d(x, w, b, 1, 1), want, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pack_conv_layout(dtype):
+    """w[n][(kh*KW + kw)*cin_pad + ci], zero padded in ci, K and n."""
+    w = torch.randn(10, 12, 3, 3)
+    b = torch.randn(10)
+    pk = ops.pack_conv(w, b, dtype, cin_pad=16)
+    ge = 8 if dtype == torch.bfloat16 else 4
+    assert pk.n == 16 and pk.cin == 16 and pk.kpad % (8 * ge) == 0 and pk.kpad >= 144 and pk.w.dtype == dtype
+    full = pk.w.float()
+    for (n, kh, kw, ci) in [(0, 0, 0, 0), (9, 2, 1, 11), (3, 1, 2, 5)]:
+        assert full[n, (kh * 3 + kw) * 16 + ci] == w[n, ci, kh, kw].to(dtype).float()
+    assert full[:, 144:].abs().max() == 0 and full[10:].abs().max() == 0
+    assert full.view(16, -1)[:, :144].view(16, 9, 16)[:, :, 12:].abs().max() == 0
+    assert torch.equal(pk.bias[:10], b) and pk.bias[10:].abs().max() == 0
+    assert pk.flops_per_row == 2 * 10 * 9 * 12
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library must load (no GPU needed) and export exactly what include/cft_hip.h declares."""
+    lib = _lib.load()
+    assert lib.cft_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "cft_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(cft_\w+)\s*\(", header, re.M))
+    assert declared == set(_lib.SIGNATURES) | {"cft_last_error"}, declared ^ (set(_lib.SIGNATURES) | {"cft_last_error"})
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+
+
+def test_bad_arguments_return_error_codes_without_gpu():
+    lib = _lib.load()
+    st = lib.cft_conv2d(None, None, None, None, None, 1, 8, 8, 8, 8, 0, 8, 64, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, None)
+    assert st == -1 and b"null pointer" in lib.cft_last_error()
+    st = lib.cft_layernorm(1, 1, 1, 1, 4, 6, 1e-5, 0, None)     # C not a multiple of 4; rejected before any launch
+    assert st == -1
+
+
+def test_no_cpu_fallback():
+    m = Model(configs.named_config("cfg1"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 3, 64, 64))
+    m.train()
+    with pytest.raises(RuntimeError):
+        m.model[1](torch.zeros(1, 32, 8, 8))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "multispectral-object-detection_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
