@@ -59,22 +59,32 @@ def gemm_family_time(model, rgb, ir):
     return n, flops, secs, fam
 
 
-def cpu_baseline(cfg, sd, height, width, batch, iters):
-    """Reported baseline only: the oracle (port of the reference forward) on the host cores."""
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(cfg, sd, height, width, budget_s=20.0):
+    """Reported baseline only: the oracle (port of the reference forward) on the host cores, torch's
+    default intra-op thread count (NOT os.cpu_count(): the box may expose more CPUs than the
+    container may use).  Bounded: one warm-up pair, then batches of 2 until ~budget_s is spent."""
     from oracle.cft_oracle import OracleModel
-    torch.set_num_threads(os.cpu_count() or 1)
-    rgb, ir = seeded_inputs(batch, height, width, seed=0)
+    rgb, ir = seeded_inputs(2, height, width, seed=0)
     om = OracleModel(cfg)
+    t0 = time.perf_counter()
     om(sd, rgb[:1], ir[:1])
+    warm = time.perf_counter() - t0
     times = []
-    for _ in range(iters):
+    spent = 0.0
+    while not times or (spent + statistics.median(times) < budget_s and len(times) < 9):
         t0 = time.perf_counter()
         om(sd, rgb, ir)
         times.append(time.perf_counter() - t0)
+        spent += times[-1]
     med = statistics.median(times)
-    return {"value": batch / med, "unit": "image-pairs/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fp32, yolov5l+CFTx3 {height}x{width}, batch {batch}, median of {iters} forwards "
-                      f"({med:.2f} s each)"}
+    return {"value": round(2 / med, 3), "unit": "image-pairs/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/cft_oracle.py fp32, same network and {height}x{width} inputs, batch 2, median of "
+                      f"{len(times)} forwards ({med:.2f} s each; first call {warm:.2f} s for 1 pair); "
+                      f"os.cpu_count()={os.cpu_count()}"}
 
 
 def main():
@@ -97,6 +107,7 @@ def main():
     torch.cuda.set_device(dev)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
+    log(f"rank {rank}/{world} building {args.config}")
     cfg = named_config(args.config)
     model = Model(cfg)
     sd = seeded_state_dict(model.state_dict(), seed=0)      # random-init weights, BN/pos_emb non-trivial
@@ -105,6 +116,7 @@ def main():
     rgb, ir = seeded_inputs(args.batch, args.size, args.size, seed=rank)
     rgb, ir = rgb.to(dev), ir.to(dev)
 
+    log("weights loaded, packing + capturing")
     with torch.no_grad():
         if args.no_graph:
             step_fn = lambda: model.forward_once(rgb, ir)   # noqa: E731
@@ -124,6 +136,8 @@ def main():
             if world > 1:
                 D.gather_equal(p, gathered)
 
+        torch.cuda.synchronize()
+        log("first step done, warming up")
         for _ in range(args.warmup):
             step()
         if world > 1:
@@ -141,11 +155,13 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(pred).all(), "non-finite detections"
+    log(f"timed region: {elapsed:.3f} s for {args.steps} steps")
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * args.batch * args.steps / elapsed
         n_launch, flops, secs, fam = gemm_family_time(model, rgb, ir)
+        log(f"gemm family: {n_launch} launches, {secs * 1e3:.2f} ms, {flops / secs / 1e12:.1f} TFLOP/s")
         top = sorted(fam.items(), key=lambda kv: -kv[1][2])[:6]
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
         achieved = flops / secs / 1e12
@@ -168,7 +184,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, {k: v for k, v in model.cpu().state_dict().items()},
-                                                args.size, args.size, batch=2, iters=3)
+                                                args.size, args.size)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -7,6 +7,11 @@ import ctypes
 import os
 import subprocess
 
+# torch must be imported BEFORE the library is dlopen'ed: torch ships its own libamdhip64 and a
+# process that first loads the system copy (through libcft_hip.so) and then torch's ends up with
+# two HIP runtimes ("No HIP GPUs are available").  Loaded in this order both bind to torch's copy.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcft_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
