@@ -61,6 +61,10 @@ int cft_conv2d(const void* x, const void* w, const float* bias, const void* res,
                int ldy, int yoff, int ldr, int roff,
                int act, int dtype, int out_dtype, int res_dtype, void* stream);
 
+/* Tuning knob: force one tile configuration of cft_conv2d (0 = automatic, the default; see
+ * csrc/conv_gemm.hip for the table).  Returns the previous value.  Not needed for normal use. */
+int cft_set_conv_variant(int variant);
+
 /*
  * Focus space-to-depth (models/common.py:176-179, the torch.cat of four strided slices):
  *   out[b, y, x, q*3 + c] = in[b, c, 2y+dy, 2x+dx],  q = dy + 2*dx, channels 12..15 = 0

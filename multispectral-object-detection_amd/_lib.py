@@ -28,6 +28,7 @@ SIGNATURES = {
     "cft_abi_version": [],
     "cft_device_check": [],
     "cft_conv2d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_set_conv_variant": [_i],
     "cft_focus_s2d": [_vp, _vp, _i, _i, _i, _i, _vp],
     "cft_spp_maxpool": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_copy_channels": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -17,8 +17,11 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// two floats -> packed bf16 pair with the hardware round-to-nearest-even convert (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
 // Element traits: T = uint16_t (bf16 bits) or float.

@@ -9,21 +9,24 @@
 //   (a 16-byte granule never straddles a tap because Cin % granule == 0); out-of-image taps
 //   and the K tail read as zero.
 //
-// Tiling (per 256-thread workgroup = 4 wave64 as 2x2):
-//   BM x BN output tile, K step = 128 bytes per row (64 bf16 / 32 f32) = 8 granules.
-//   global -> registers (16-B loads, 8 consecutive lanes cover one 128-B row segment)
-//          -> LDS (row-major 128-B rows, granule index XOR (row & 7): conflict-free
-//             ds_read_b128 fragment reads)  -> MFMA.
+// Tiling: BM x BN output tile per workgroup of WGM x WGN wave64s (each wave a (BM/WGM)x(BN/WGN)
+//   sub-tile of 16x16 MFMA tiles), K step = 128 bytes per row (64 bf16 / 32 f32) = 8 granules.
+//   LDS image: row-major 128-B rows, the 16-B granule slot index XOR (row & 7) -> conflict-free
+//   ds_read_b128 fragment reads.  Two staging paths:
+//     GLDS = true  global_load_lds_dwordx4: HBM/L2 -> LDS directly.  The LDS destination of that
+//                  instruction is wave-uniform base + lane*16, i.e. linear, so the XOR swizzle is
+//                  applied on the SOURCE side: lane (row r, slot s) fetches k-granule s ^ (r & 7).
+//                  Masked granules (image border, K tail, N tail) fetch from a zero page.
+//     GLDS = false global -> VGPR -> ds_write_b128 (register staging, loads issued one K step ahead)
+//   Double-buffered, one barrier per K step.
 //   bf16: v_mfma_f32_16x16x32_bf16 (lane holds 8 consecutive k of one row = one granule);
 //   f32 : 4 x v_mfma_f32_16x16x4_f32 per granule (exact fp32 products, fp32 accumulate).
 //   Both operands use the same (lane-group, element) -> k assignment, so the reduction is a
 //   permutation of k and needs no knowledge of the instruction's internal k order.
-//   Double-buffered LDS, next tile's global loads are issued before the MFMAs of the current
-//   one; one barrier per K step.
-// Epilogue: acc (+bias, activation) -> per-wave LDS strip (fp32) -> rows re-read as 16-B
-//   vectors -> (+residual) -> one rounding -> coalesced 16-B global stores.
-// Workgroup order is remapped so that consecutive logical tiles (which share the A rows or
-// neighbouring image rows) run on the same XCD and hit the same 4 MiB L2.
+// Epilogue (wave-private, no workgroup barriers): acc (+bias, activation) -> 16-row fp32 LDS strip
+//   -> rows re-read as 16-B vectors -> (+residual) -> one rounding -> coalesced 16-B stores.
+// Workgroup order is remapped so that consecutive logical tiles (which share A rows / neighbouring
+// image rows) run on the same XCD and hit the same 4 MiB L2.
 #include "cft_common.h"
 
 struct ConvParams {
@@ -38,132 +41,35 @@ struct ConvParams {
   int KS, stride, pad;
   int act, out_f32, res_f32;
   int M, tilesN;
+  uint32_t wo_mul, wo_sh, ho_mul, ho_sh;   // exact n / Wo and n / Ho for n < 2^31 as umulhi(n, mul) >> sh (mul == 0: divisor 1)
 };
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == CFT_ACT_SILU) return v / (1.0f + __expf(-v));
-  if (act == CFT_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+// floor(n / d) for 0 <= n < 2^31 with a host-computed (mul, sh): Granlund-Montgomery round-up method.
+__device__ __forceinline__ int fast_div(int n, uint32_t mul, uint32_t sh) {
+  return mul ? (int)(__umulhi((uint32_t)n, mul) >> sh) : n;
+}
+
+__device__ __attribute__((aligned(16))) uint32_t cft_zero_page[4] = {0u, 0u, 0u, 0u};
+
+template <int ACT>
+__device__ __forceinline__ float apply_act(float v) {
+  if constexpr (ACT == CFT_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));   // x*sigmoid(x): v_exp + v_rcp
+  if constexpr (ACT == CFT_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
   return v;
 }
 
-template <typename T, int BM, int BN>
-__global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvParams p) {
-  constexpr int GE = Elem<T>::GE;
-  constexpr int BK = 8 * GE;
-  constexpr int A_PER = BM / 32, B_PER = BN / 32;
-  constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-  constexpr int ES = (int)sizeof(T);
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;
-  unsigned char* sB = smem + 2 * A_BYTES;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-  // ---- XCD-aware tile assignment (bijective for any grid size) ----
-  const int nb = gridDim.x, bid = blockIdx.x;
-  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, slot = bid >> 3;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  const int tm = logical / p.tilesN, tn = logical - tm * p.tilesN;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int g = tid & 7, r0 = tid >> 3;
-
-  // ---- per-thread gather state: A_PER pixel rows, one k-granule column g ----
-  int a_off[A_PER];
-  uint32_t a_mask[A_PER];
-#pragma unroll
-  for (int i = 0; i < A_PER; ++i) {
-    const int m = m0 + r0 + i * 32;
-    a_off[i] = 0;
-    a_mask[i] = 0;
-    if (m < p.M) {
-      const int wo = m % p.Wo;
-      const int t = m / p.Wo;
-      const int ho = t % p.Ho;
-      const int b = t / p.Ho;
-      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-      a_off[i] = ((b * p.H + hi0) * p.W + wi0) * p.ldx + p.xoff;
-      uint32_t mk = 0;
-      for (int kh = 0; kh < p.KS; ++kh)
-        for (int kw = 0; kw < p.KS; ++kw)
-          if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W) mk |= 1u << (kh * p.KS + kw);
-      a_mask[i] = mk;
-    }
-  }
-  int ci = g * GE, kh = 0, kw = 0, tap = 0;
-  while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }
-
-  gran_t ra[A_PER], rb[B_PER];
-  const int swz = (g ^ (r0 & 7)) << 4;
-
-// Gather the next K step of this thread's A/B granules into registers, then advance (tap, ci).
-#define CFT_LOAD_TILE(kt_)                                                                             \
-  {                                                                                                    \
-    const int kglob = (kt_) * BK + g * GE;                                                             \
-    const bool kin = kglob < p.K;                                                                      \
-    const long tapoff = ((long)kh * p.W + kw) * p.ldx + ci;                                            \
-    _Pragma("unroll") for (int i = 0; i < A_PER; ++i) {                                                \
-      const bool v = kin && ((a_mask[i] >> tap) & 1u);                                                 \
-      gran_t t_ = {0u, 0u, 0u, 0u};                                                                  \
-      if (v) t_ = *reinterpret_cast<const gran_t*>(p.x + ((long)a_off[i] + tapoff) * ES);              \
-      ra[i] = t_;                                                                                      \
-    }                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < B_PER; ++i) {                                                \
-      const int n = n0 + r0 + i * 32;                                                                  \
-      gran_t t_ = {0u, 0u, 0u, 0u};                                                                  \
-      if (n < p.N) t_ = *reinterpret_cast<const gran_t*>(p.w + ((long)n * p.Kpad + kglob) * ES);      \
-      rb[i] = t_;                                                                                      \
-    }                                                                                                  \
-    ci += BK;                                                                                          \
-    while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }                    \
-  }
-#define CFT_STORE_TILE(buf_)                                                                           \
-  {                                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < A_PER; ++i)                                                  \
-      *reinterpret_cast<gran_t*>(sA + (buf_) * A_BYTES + (r0 + i * 32) * 128 + swz) = ra[i];           \
-    _Pragma("unroll") for (int i = 0; i < B_PER; ++i)                                                  \
-      *reinterpret_cast<gran_t*>(sB + (buf_) * B_BYTES + (r0 + i * 32) * 128 + swz) = rb[i];           \
-  }
-
-  f32x4_t acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.Kpad / BK;
-  CFT_LOAD_TILE(0)
-  CFT_STORE_TILE(0)
-  __syncthreads();
+// Epilogue (wave-private, no workgroup barriers - the LDS operations of one wave are ordered):
+// acc (+bias, activation) -> 16-row fp32 LDS strip -> rows re-read as 16-B vectors -> (+residual)
+// -> one rounding -> coalesced 16-B stores.  The caller guarantees (barrier) that no wave still
+// reads the staging buffers that the strips alias.
+template <int WM, int WN, int ACT, bool OUT_F32>
+__device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4_t (&acc)[WM / 16][WN / 16], unsigned char* smem,
+                                                   int m0, int n0, int wm, int wn, int wave, int lane) {
+  constexpr int MT = WM / 16, NT = WN / 16;
   const int lrow = lane & 15, lgrp = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) CFT_LOAD_TILE(kt + 1)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kg = ks * 4 + lgrp;
-      gran_t af[MT], bf[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = wm * WM + i * 16 + lrow;
-        af[i] = *reinterpret_cast<const gran_t*>(sA + buf * A_BYTES + row * 128 + ((kg ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int row = wn * WN + j * 16 + lrow;
-        bf[j] = *reinterpret_cast<const gran_t*>(sB + buf * B_BYTES + row * 128 + ((kg ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = mma_granule<T>(af[i], bf[j], acc[i][j]);
-    }
-    if (kt + 1 < nk) CFT_STORE_TILE(buf ^ 1)
-    __syncthreads();
-  }
-
-  // ---- epilogue ----
   constexpr int SLD = WN + 4;  // fp32 strip leading dimension (+4: the four 4-row lane groups hit different banks)
   float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SLD);
   float bias_v[NT];
@@ -178,11 +84,13 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvParams p) {
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        stage[(lgrp * 4 + e) * SLD + j * 16 + lrow] = apply_act(acc[i][j][e] + bias_v[j], p.act);
-    __syncthreads();
+        stage[(lgrp * 4 + e) * SLD + j * 16 + lrow] = apply_act<ACT>(acc[i][j][e] + bias_v[j]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int mbase = m0 + wm * WM + i * 16;
     const int nbase = n0 + wn * WN;
-    if (p.out_f32) {
+    if constexpr (OUT_F32) {
       constexpr int VPR = WN / 4;  // 16-B vectors per strip row
       for (int it = lane; it < 16 * VPR; it += 64) {
         const int row = it / VPR, col = (it - row * VPR) * 4;
@@ -232,36 +140,425 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvParams p) {
         }
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
+// Uniform dispatch to the specialised epilogues (one activation / output type per launch).
+template <int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc)[WM / 16][WN / 16], unsigned char* smem,
+                                              int m0, int n0, int wm, int wn, int wave, int lane) {
+  if (p.out_f32) {
+    if (p.act == CFT_ACT_SILU) conv_epilogue_impl<WM, WN, CFT_ACT_SILU, true>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+    else if (p.act == CFT_ACT_GELU) conv_epilogue_impl<WM, WN, CFT_ACT_GELU, true>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+    else conv_epilogue_impl<WM, WN, CFT_ACT_NONE, true>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+  } else {
+    if (p.act == CFT_ACT_SILU) conv_epilogue_impl<WM, WN, CFT_ACT_SILU, false>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+    else if (p.act == CFT_ACT_GELU) conv_epilogue_impl<WM, WN, CFT_ACT_GELU, false>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+    else conv_epilogue_impl<WM, WN, CFT_ACT_NONE, false>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+  }
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS>
+__global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvParams p) {
+  constexpr int NTHR = 64 * WGM * WGN;
+  constexpr int GE = Elem<T>::GE;
+  constexpr int BK = 8 * GE;
+  constexpr int RPP = NTHR / 8;  // tile rows staged per pass of the whole workgroup
+  constexpr int A_PER = BM / RPP, B_PER = (BN + RPP - 1) / RPP;   // BN < RPP: only the first BN rows' threads stage B
+  constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 16, NT = WN / 16;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int ES = (int)sizeof(T);
+  static_assert(BM % RPP == 0 && (BN % RPP == 0 || BN < RPP) && WM % 16 == 0 && WN % 16 == 0, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 2 * A_BYTES;
+
+  // ---- XCD-aware tile assignment (bijective for any grid size) ----
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, slot = bid >> 3;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  const int tm = logical / p.tilesN, tn = logical - tm * p.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave - wm * WGN;
+  const int r0 = tid >> 3;                               // tile row within a pass
+  const int slot_s = tid & 7;                            // LDS slot this thread fills
+  const int g = GLDS ? (slot_s ^ (r0 & 7)) : slot_s;     // k-granule this thread fetches
+
+  // ---- per-thread gather state: A_PER pixel rows, one k-granule column g ----
+  int a_off[A_PER];
+  uint32_t a_mask[A_PER];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int m = m0 + r0 + i * RPP;
+    a_off[i] = 0;
+    a_mask[i] = 0;
+    if (m < p.M) {
+      const int t = fast_div(m, p.wo_mul, p.wo_sh);
+      const int wo = m - t * p.Wo;
+      const int b = fast_div(t, p.ho_mul, p.ho_sh);
+      const int ho = t - b * p.Ho;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      a_off[i] = ((b * p.H + hi0) * p.W + wi0) * p.ldx + p.xoff;
+      uint32_t wbits = 0, mk = 0;   // tap validity = (row kh in image) x (column kw in image)
+      for (int kw = 0; kw < p.KS; ++kw) wbits |= ((unsigned)(wi0 + kw) < (unsigned)p.W ? 1u : 0u) << kw;
+      for (int kh = 0; kh < p.KS; ++kh)
+        if ((unsigned)(hi0 + kh) < (unsigned)p.H) mk |= wbits << (kh * p.KS);
+      a_mask[i] = mk;
+    }
+  }
+  int ci = g * GE, kh = 0, kw = 0, tap = 0;
+  while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }
+
+  gran_t ra[GLDS ? 1 : A_PER], rb[GLDS ? 1 : B_PER];
+  const int swz = (slot_s ^ (r0 & 7)) << 4;              // register path: where this thread's granule lands
+  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(cft_zero_page);
+
+// Fetch K step kt_ of this thread's A/B granules (into LDS buffer buf_ when GLDS, else into
+// registers), then advance (tap, ci).
+#define CFT_LOAD_TILE(kt_, buf_)                                                                       \
+  {                                                                                                    \
+    const int kglob = (kt_) * BK + g * GE;                                                             \
+    const bool kin = kglob < p.K;                                                                      \
+    const long tapoff = ((long)kh * p.W + kw) * p.ldx + ci;                                            \
+    _Pragma("unroll") for (int i = 0; i < A_PER; ++i) {                                                \
+      const bool v = kin && ((a_mask[i] >> tap) & 1u);                                                 \
+      if constexpr (GLDS) {                                                                            \
+        const unsigned char* src = v ? p.x + ((long)a_off[i] + tapoff) * ES : zero_page;               \
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src,                                             \
+            (lds_void_t*)(sA + (buf_) * A_BYTES + i * (RPP * 128) + wave * 1024), 16, 0, 0);           \
+      } else {                                                                                         \
+        gran_t t_ = {0u, 0u, 0u, 0u};                                                                  \
+        if (v) t_ = *reinterpret_cast<const gran_t*>(p.x + ((long)a_off[i] + tapoff) * ES);            \
+        ra[i] = t_;                                                                                    \
+      }                                                                                                \
+    }                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < B_PER; ++i) {                                                \
+      const int n = n0 + r0 + i * RPP;                                                                 \
+      if (BN < RPP && wave * 8 >= BN) continue; /* wave-uniform: this wave has no B rows */             \
+      if constexpr (GLDS) {                                                                            \
+        const unsigned char* src = (n < p.N) ? p.w + ((long)n * p.Kpad + kglob) * ES : zero_page;      \
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src,                                             \
+            (lds_void_t*)(sB + (buf_) * B_BYTES + i * (RPP * 128) + wave * 1024), 16, 0, 0);           \
+      } else {                                                                                         \
+        gran_t t_ = {0u, 0u, 0u, 0u};                                                                  \
+        if (n < p.N) t_ = *reinterpret_cast<const gran_t*>(p.w + ((long)n * p.Kpad + kglob) * ES);    \
+        rb[i] = t_;                                                                                    \
+      }                                                                                                \
+    }                                                                                                  \
+    ci += BK;                                                                                          \
+    while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }                    \
+  }
+#define CFT_STORE_TILE(buf_)                                                                           \
+  if constexpr (!GLDS) {                                                                               \
+    _Pragma("unroll") for (int i = 0; i < A_PER; ++i)                                                  \
+      *reinterpret_cast<gran_t*>(sA + (buf_) * A_BYTES + (r0 + i * RPP) * 128 + swz) = ra[i];          \
+    _Pragma("unroll") for (int i = 0; i < B_PER; ++i)                                                  \
+      if (BN >= RPP || r0 < BN)                                                                        \
+        *reinterpret_cast<gran_t*>(sB + (buf_) * B_BYTES + (r0 + i * RPP) * 128 + swz) = rb[i];        \
+  }
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.Kpad / BK;
+  CFT_LOAD_TILE(0, 0)
+  CFT_STORE_TILE(0)
+  __syncthreads();
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) CFT_LOAD_TILE(kt + 1, buf ^ 1)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kg = ks * 4 + lgrp;
+      gran_t af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = wm * WM + i * 16 + lrow;
+        af[i] = *reinterpret_cast<const gran_t*>(sA + buf * A_BYTES + row * 128 + ((kg ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int row = wn * WN + j * 16 + lrow;
+        bf[j] = *reinterpret_cast<const gran_t*>(sB + buf * B_BYTES + row * 128 + ((kg ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mma_granule<T>(af[i], bf[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) CFT_STORE_TILE(buf ^ 1)
+    __syncthreads();
+  }
+#undef CFT_LOAD_TILE
+#undef CFT_STORE_TILE
+
+  conv_epilogue<WM, WN>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pipelined variant: STAGES-deep ring of LDS stages filled by global_load_lds, counted vmcnt and raw
+// s_barrier so that STAGES-1 K steps of loads stay in flight across the barriers (a __syncthreads()
+// would drain them: it carries vmcnt(0) while an LDS-DMA is pending).  Per K step:
+//     s_waitcnt vmcnt(own loads of later tiles)   -> this wave's part of tile kt has landed
+//     s_barrier                                   -> everybody's part has; stage (kt-1)%S is free
+//     issue loads of tile kt+S-1 into that stage
+//     MFMA on stage kt%S
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES>
+__global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_pipe_kernel(const ConvParams p) {
+  constexpr int NTHR = 64 * WGM * WGN;
+  constexpr int GE = Elem<T>::GE;
+  constexpr int BK = 8 * GE;
+  constexpr int RPP = NTHR / 8;
+  constexpr int A_PER = BM / RPP, B_PER = BN / RPP, LPT = A_PER + B_PER;
+  constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 16, NT = WN / 16;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int ES = (int)sizeof(T);
+  static_assert(BM % RPP == 0 && BN % RPP == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
+  static_assert(STAGES >= 2 && STAGES <= 4 && LPT * (STAGES - 2) < 64, "pipeline depth");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, slot = bid >> 3;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  const int tm = logical / p.tilesN, tn = logical - tm * p.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave - wm * WGN;
+  const int r0 = tid >> 3;
+  const int g = (tid & 7) ^ (r0 & 7);   // source-side swizzle: slot s of row r holds k-granule s ^ (r & 7)
+
+  const unsigned char* a_ptr[A_PER];
+  uint32_t a_mask[A_PER];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int m = m0 + r0 + i * RPP;
+    a_ptr[i] = p.x;
+    a_mask[i] = 0;
+    if (m < p.M) {
+      const int t = fast_div(m, p.wo_mul, p.wo_sh);
+      const int wo = m - t * p.Wo;
+      const int b = fast_div(t, p.ho_mul, p.ho_sh);
+      const int ho = t - b * p.Ho;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      a_ptr[i] = p.x + ((long)((b * p.H + hi0) * p.W + wi0) * p.ldx + p.xoff) * ES;
+      uint32_t wbits = 0, mk = 0;   // tap validity = (row kh in image) x (column kw in image)
+      for (int kw = 0; kw < p.KS; ++kw) wbits |= ((unsigned)(wi0 + kw) < (unsigned)p.W ? 1u : 0u) << kw;
+      for (int kh = 0; kh < p.KS; ++kh)
+        if ((unsigned)(hi0 + kh) < (unsigned)p.H) mk |= wbits << (kh * p.KS);
+      a_mask[i] = mk;
+    }
+  }
+  const unsigned char* b_ptr[B_PER];
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const int n = n0 + r0 + i * RPP;
+    b_ptr[i] = (n < p.N) ? p.w + ((long)n * p.Kpad + g * GE) * ES : nullptr;
+  }
+  int ci = g * GE, kh = 0, kw = 0, tap = 0;
+  while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }
+  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(cft_zero_page);
+
+#define CFT_ISSUE_TILE(kt_, st_)                                                                       \
+  {                                                                                                    \
+    const bool kin = ((kt_) * BK + g * GE) < p.K;                                                      \
+    const long tapoff = (((long)kh * p.W + kw) * p.ldx + ci) * ES;                                     \
+    unsigned char* stg = smem + (st_) * STAGE_BYTES + wave * 1024;                                     \
+    _Pragma("unroll") for (int i = 0; i < A_PER; ++i) {                                                \
+      const bool v = kin && ((a_mask[i] >> tap) & 1u);                                                 \
+      const unsigned char* src = v ? a_ptr[i] + tapoff : zero_page;                                    \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stg + i * (RPP * 128)), 16, 0, 0); \
+    }                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < B_PER; ++i) {                                                \
+      const unsigned char* src = b_ptr[i] ? b_ptr[i] + (long)(kt_) * (BK * ES) : zero_page;            \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stg + A_BYTES + i * (RPP * 128)), 16, 0, 0); \
+    }                                                                                                  \
+    ci += BK;                                                                                          \
+    while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }                    \
+  }
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.Kpad / BK;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) CFT_ISSUE_TILE(s, s)
+
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  int st = 0;                 // stage holding tile kt
+  int st_free = STAGES - 1;   // stage that tile kt+STAGES-1 goes to
+  for (int kt = 0; kt < nk; ++kt) {
+    const int later = nk - 1 - kt;   // tiles after kt that exist; min(later, STAGES-2) of them are already issued
+    if (STAGES >= 4 && later >= 2) wait_vmcnt<(STAGES >= 4 ? 2 : 0) * LPT>();
+    else if (STAGES >= 3 && later >= 1) wait_vmcnt<(STAGES >= 3 ? 1 : 0) * LPT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + STAGES - 1 < nk) CFT_ISSUE_TILE(kt + STAGES - 1, st_free)
+    const unsigned char* sA = smem + st * STAGE_BYTES;
+    const unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kg = ks * 4 + lgrp;
+      gran_t af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = wm * WM + i * 16 + lrow;
+        af[i] = *reinterpret_cast<const gran_t*>(sA + row * 128 + ((kg ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int row = wn * WN + j * 16 + lrow;
+        bf[j] = *reinterpret_cast<const gran_t*>(sB + row * 128 + ((kg ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mma_granule<T>(af[i], bf[j], acc[i][j]);
+    }
+    st_free = st;
+    st = (st + 1 == STAGES) ? 0 : st + 1;
+  }
+#undef CFT_ISSUE_TILE
+  __syncthreads();   // all waves are done reading the stages the epilogue strips alias
+  conv_epilogue<WM, WN>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+}
+
 // ------------------------------------------------------------------------------------ host
-template <typename T, int BM, int BN>
+// (mul, sh) with floor(n / d) == umulhi(n, mul) >> sh for all 0 <= n < 2^31 (d >= 2); mul = 0 encodes d == 1.
+static void set_magic(int d, uint32_t& mul, uint32_t& sh) {
+  if (d <= 1) { mul = 0; sh = 0; return; }
+  int l = 0;
+  while ((1L << l) < d) ++l;                         // l = ceil(log2 d)
+  const unsigned long long k = 31ULL + l;           // 2^k / d < 2^32
+  mul = (uint32_t)(((1ULL << k) / (unsigned long long)d) + 1ULL);
+  sh = (uint32_t)(k - 32);
+}
+
+// Tile variants.  0 = automatic choice; the others force one configuration (tuning / A-B tests).
+static int g_conv_variant = 0;
+extern "C" int cft_set_conv_variant(int v) {
+  const int old = g_conv_variant;
+  g_conv_variant = v;
+  return old;
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
   constexpr int smem_bytes = 2 * (BM + BN) * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     attr_done = true;
   }
   ConvParams q = p;
   const int tilesM = (p.M + BM - 1) / BM;
   q.tilesN = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN>), dim3(tilesM * q.tilesN), dim3(256), smem_bytes, stream, q);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS>), dim3(tilesM * q.tilesN), dim3(64 * WGM * WGN), smem_bytes, stream, q);
   return cft_check_launch("conv_gemm_kernel");
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES>
+static int launch_pipe(const ConvParams& p, hipStream_t stream) {
+  constexpr int smem_bytes = STAGES * (BM + BN) * 128;
+  static_assert(smem_bytes <= 160 * 1024, "LDS budget");
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_pipe_kernel<T, BM, BN, WGM, WGN, STAGES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    attr_done = true;
+  }
+  ConvParams q = p;
+  const int tilesM = (p.M + BM - 1) / BM;
+  q.tilesN = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL((conv_gemm_pipe_kernel<T, BM, BN, WGM, WGN, STAGES>), dim3(tilesM * q.tilesN), dim3(64 * WGM * WGN), smem_bytes, stream, q);
+  return cft_check_launch("conv_gemm_pipe_kernel");
 }
 
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
-  // Tile choice: BN = 64 for narrow outputs; BM = 64 when 128-row tiles would leave most of the
-  // 256 CUs idle (deep layers at small batch).
-  const bool narrow = p.N <= 64;
-  const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
-  const bool small = tiles128 < 384;
-  if (narrow) return small ? launch_conv<T, 64, 64>(p, stream) : launch_conv<T, 128, 64>(p, stream);
-  return small ? launch_conv<T, 64, 128>(p, stream) : launch_conv<T, 128, 128>(p, stream);
+  switch (g_conv_variant) {
+    case 10: return launch_pipe<T, 256, 128, 4, 2, 3>(p, stream);
+    case 11: return launch_pipe<T, 128, 128, 2, 2, 3>(p, stream);
+    case 12: return launch_pipe<T, 128, 128, 2, 2, 2>(p, stream);
+    case 13: return launch_pipe<T, 256, 64, 4, 2, 3>(p, stream);
+    case 14: return launch_pipe<T, 256, 64, 4, 2, 4>(p, stream);
+    case 15: return launch_pipe<T, 128, 64, 2, 2, 3>(p, stream);
+    case 16: return launch_pipe<T, 128, 64, 2, 2, 4>(p, stream);
+    case 17: return launch_pipe<T, 256, 128, 4, 2, 2>(p, stream);
+    case 18: return launch_pipe<T, 128, 256, 2, 4, 3>(p, stream);
+    case 19: return launch_pipe<T, 128, 128, 2, 2, 4>(p, stream);
+    case 20: return launch_pipe<T, 256, 128, 2, 2, 3>(p, stream);
+    case 21: return launch_pipe<T, 256, 256, 2, 4, 2>(p, stream);
+    case 1: return launch_conv<T, 128, 128, 2, 2, false>(p, stream);
+    case 2: return launch_conv<T, 128, 128, 2, 2, true>(p, stream);
+    case 3: return launch_conv<T, 128, 64, 2, 2, false>(p, stream);
+    case 4: return launch_conv<T, 128, 64, 2, 2, true>(p, stream);
+    case 5: return launch_conv<T, 256, 128, 4, 2, true>(p, stream);
+    case 6: return launch_conv<T, 256, 64, 4, 2, true>(p, stream);
+    case 7: return launch_conv<T, 64, 128, 2, 2, true>(p, stream);
+    case 8: return launch_conv<T, 64, 64, 2, 2, true>(p, stream);
+    case 9: return launch_conv<T, 128, 256, 2, 4, true>(p, stream);
+    case 22: return launch_conv<T, 128, 128, 4, 2, true>(p, stream);
+    case 23: return launch_conv<T, 128, 128, 2, 4, true>(p, stream);
+    case 24: return launch_conv<T, 256, 128, 4, 4, true>(p, stream);
+    case 25: return launch_conv<T, 256, 128, 8, 2, true>(p, stream);
+    case 26: return launch_conv<T, 128, 64, 4, 2, true>(p, stream);
+    case 27: return launch_conv<T, 256, 256, 4, 4, true>(p, stream);
+    case 29: return launch_conv<T, 128, 256, 4, 4, true>(p, stream);
+    case 30: return launch_conv<T, 512, 128, 8, 2, true>(p, stream);
+    case 31: return launch_conv<T, 256, 256, 2, 4, true>(p, stream);
+    case 32: return launch_conv<T, 512, 64, 8, 2, true>(p, stream);
+    case 33: return launch_conv<T, 256, 128, 4, 2, true>(p, stream);
+    case 34: return launch_conv<T, 256, 64, 4, 4, true>(p, stream);
+    case 35: return launch_conv<T, 128, 64, 4, 1, true>(p, stream);
+    default: break;
+  }
+  // Automatic choice (measured on MI355X with tools/gemm_bench.py, yolov5l+CFTx3 layer shapes, bf16):
+  //  * the more waves per CU the better the latency hiding: 16-wave workgroups with 64x64 wave tiles
+  //    (256x256 for wide layers, 512x128 for 128-channel layers) reach 0.9-1.1 PFLOP/s on K >= 1152;
+  //  * HBM-bound layers (1x1, K <= 256) run best on 8-wave 128x128 / 256x64 tiles (4.3-4.8 TB/s);
+  //  * a tile configuration is only used if it yields at least one workgroup per CU.
+  auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  const long kCUs = 192;   // accept a configuration once it yields >= 0.75 workgroups per CU (256 CUs)
+  if (p.N <= 64) {
+    if (tiles(256, 64) >= kCUs) return launch_conv<T, 256, 64, 4, 2, true>(p, stream);
+    if (tiles(128, 64) >= kCUs) return launch_conv<T, 128, 64, 2, 2, true>(p, stream);
+    return launch_conv<T, 64, 64, 2, 2, true>(p, stream);
+  }
+  if (p.N <= 128) {
+    if (p.Kpad >= 512 && tiles(512, 128) >= kCUs) return launch_conv<T, 512, 128, 8, 2, true>(p, stream);
+    if (tiles(128, 128) >= kCUs) return launch_conv<T, 128, 128, 2, 4, true>(p, stream);
+    return launch_conv<T, 64, 128, 2, 2, true>(p, stream);
+  }
+  // wide layers: prefer 256-wide tiles unless the N tail would waste much more than 128-wide tiles do
+  const long pad256 = (long)((p.N + 255) / 256) * 256, pad128 = (long)((p.N + 127) / 128) * 128;
+  const bool wide_ok = pad256 * 100 <= pad128 * 115;
+  if (wide_ok && p.Kpad >= 256 && tiles(256, 256) >= kCUs) return launch_conv<T, 256, 256, 4, 4, true>(p, stream);
+  if (p.Kpad >= 512 && tiles(512, 128) >= kCUs) return launch_conv<T, 512, 128, 8, 2, true>(p, stream);
+  if (p.Kpad >= 512 && tiles(256, 128) >= kCUs) return launch_conv<T, 256, 128, 4, 2, true>(p, stream);
+  if (tiles(128, 128) >= kCUs) return launch_conv<T, 128, 128, 2, 4, true>(p, stream);
+  return launch_conv<T, 64, 128, 2, 2, true>(p, stream);
 }
 
 extern "C" int cft_conv2d(const void* x, const void* w, const float* bias, const void* res, void* y,
@@ -294,5 +591,7 @@ extern "C" int cft_conv2d(const void* x, const void* w, const float* bias, const
   p.KS = ksize; p.stride = stride; p.pad = pad;
   p.act = act; p.out_f32 = out_dtype == CFT_F32; p.res_f32 = res_dtype == CFT_F32;
   p.M = (int)M; p.tilesN = 0;
+  set_magic(Wo, p.wo_mul, p.wo_sh);
+  set_magic(Ho, p.ho_mul, p.ho_sh);
   return dtype == CFT_BF16 ? dispatch_conv<uint16_t>(p, as_stream(stream)) : dispatch_conv<float>(p, as_stream(stream));
 }

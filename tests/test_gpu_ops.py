@@ -258,3 +258,30 @@ def test_errors_are_loud(dev):
         ops.conv2d(torch.zeros(1, 8, 4, 4, dtype=torch.bfloat16), pk, 0)     # CPU tensor
     with pytest.raises(TypeError):
         ops.conv2d(torch.zeros(1, 8, 4, 4, device=dev, dtype=torch.float16), pk, 0)
+
+
+TILE_VARIANTS = [1, 2, 4, 6, 7, 8, 9, 17, 22, 23, 24, 27, 29, 30, 32, 33, 35]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("variant", TILE_VARIANTS)
+def test_conv2d_every_tile_configuration(dev, dtype, variant):
+    """Every tile configuration of the GEMM family (incl. the 16-wave 256x256 / 512x128 ones that the
+    dispatcher only picks at large batch) on a problem with ragged M (2*33*31 rows), an N tail
+    (320 = 256 + 64) and border taps; all must agree with the oracle."""
+    from msod_amd import _lib, ops
+    B, H, W, Cin, Cout, k = 2, 33, 31, 64, 320, 3
+    x = _q(_rnd(B, Cin, H, W, seed=31), dtype)
+    w = _q(_rnd(Cout, Cin, k, k, seed=32, scale=1.0 / math.sqrt(Cin * k * k)), dtype)
+    b = _rnd(Cout, seed=33, scale=0.5)
+    res = _q(_rnd(B, Cout, H, W, seed=34), dtype)
+    ref = F.silu(F.conv2d(x, w, b, 1, 1)) + res
+    pk = ops.pack_conv(w, b, dtype, device=dev)
+    lib = _lib.load()
+    lib.cft_set_conv_variant(variant)
+    try:
+        y = ops.conv2d(to_dev_nhwc(x, dev, dtype), pk, 1, residual=to_dev_nhwc(res, dev, dtype))
+        torch.cuda.synchronize()
+    finally:
+        lib.cft_set_conv_variant(0)
+    assert rel_err(to_cpu_f32(y), ref) < tol(dtype), f"variant {variant}: rel err {rel_err(to_cpu_f32(y), ref):.3e}"
