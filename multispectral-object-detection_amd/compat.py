@@ -1,0 +1,60 @@
+"""Make this package answer to the reference's module names.
+
+The reference's callers (`train.py:26-27`, `test.py`, `detect_twostream.py`) do
+``from models.yolo_test import Model`` / ``from models.common import *`` and its checkpoints are
+pickled whole ``nn.Module`` objects (``train.py:850-860``) whose classes are recorded as
+``models.yolo_test.Model`` and ``models.common.<Class>``.  After
+``install_reference_aliases()`` those names resolve to the MI355X-native classes, so
+
+    import msod_amd.compat as c; c.install_reference_aliases()
+    from models.yolo_test import Model            # -> msod_amd.models.yolo_test.Model
+    ckpt = torch.load("best.pt", weights_only=False)   # un-pickles into the HIP-backed modules
+
+works without touching the caller.  (Un-pickling restores parameters and buffers; the kernel-side
+packed weights are rebuilt lazily on first forward.)
+"""
+import sys
+import types
+
+
+def install_reference_aliases(force=False):
+    from .models import common, yolo_test
+    for name, mod in (("models.common", common), ("models.yolo_test", yolo_test)):
+        if name in sys.modules and sys.modules[name] is not mod and not force:
+            raise RuntimeError(f"{name} is already imported from {getattr(sys.modules[name], '__file__', '?')}; "
+                               "pass force=True to override it")
+        sys.modules[name] = mod
+    pkg = sys.modules.get("models")
+    if pkg is None or force:
+        pkg = types.ModuleType("models")
+        pkg.__path__ = []
+        sys.modules["models"] = pkg
+    pkg.common = common
+    pkg.yolo_test = yolo_test
+    return pkg
+
+
+def attempt_load(weights, map_location=None):
+    """Single-checkpoint form of the reference's ``attempt_load`` (models/experimental.py:113-134):
+    load a pickled checkpoint, take ``ema`` or ``model``, ``.float().fuse().eval()``."""
+    import torch
+    install_reference_aliases()
+    ckpt = torch.load(weights, map_location=map_location, weights_only=False)
+    model = ckpt["ema" if ckpt.get("ema") else "model"] if isinstance(ckpt, dict) else ckpt
+    adopt_torch_modules(model)
+    return model.float().fuse().eval()
+
+
+def adopt_torch_modules(model):
+    """A reference pickle holds plain ``torch.nn.Upsample`` layers (yaml rows 33/37); swap them for
+    the HIP-backed subclass, keeping the parse_model tags."""
+    import torch.nn as nn
+    from .models.common import Upsample
+    for name, child in list(model.model.named_children()):
+        if type(child) is nn.Upsample:
+            new = Upsample(child.size, child.scale_factor, child.mode)
+            for tag in ("i", "f", "type", "np"):
+                if hasattr(child, tag):
+                    setattr(new, tag, getattr(child, tag))
+            model.model._modules[name] = new
+    return model

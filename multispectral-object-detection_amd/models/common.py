@@ -211,13 +211,14 @@ class SPP(nn.Module):
 
     def forward(self, x):
         x = resolve(x)
-        if len(self.k) != 3 or list(self.k) != sorted(self.k):
+        ks = tuple(int(mp.kernel_size) for mp in self.m)   # (not self.k: un-pickled reference modules lack it)
+        if len(ks) != 3 or list(ks) != sorted(ks):
             raise NotImplementedError("SPP kernel implements exactly three ascending pooling sizes")
         c_ = self.cv1.conv.out_channels
         B, _, H, W = x.shape
         cat = ops.new_nhwc(B, H, W, 4 * c_, x.dtype, x.device)
         self.cv1(x, out=cat[:, :c_])
-        ops.spp_maxpool(cat, c_, self.k)
+        ops.spp_maxpool(cat, c_, ks)
         return self.cv2(cat)
 
 

@@ -181,6 +181,12 @@ class Model(nn.Module):
         self.compute_dtype = torch.bfloat16
         self.eval()
 
+    def __setstate__(self, state):
+        """Un-pickling a checkpoint written by the reference restores only the reference's attributes."""
+        super().__setstate__(state)
+        self.__dict__.setdefault("_graphs", {})
+        self.__dict__.setdefault("compute_dtype", torch.bfloat16)
+
     # ---- reference-compatible API -----------------------------------------------------------
     def forward(self, x, x2, augment=False, profile=False):
         if augment:

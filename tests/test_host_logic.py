@@ -134,3 +134,34 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_reference_pickled_checkpoint_loads_into_hip_modules(tmp_path):
+    """A checkpoint pickled by the REFERENCE code (whole nn.Module, train.py:850-860) un-pickles into
+    this package's classes once the module aliases are installed, with identical parameters."""
+    import subprocess
+    import sys
+    ck = tmp_path / "ref.pt"
+    script = f"""
+import sys, types, logging, torch
+for n in ("cv2", "torchvision", "seaborn"):
+    sys.modules.setdefault(n, types.ModuleType(n))
+sys.modules["cv2"].setNumThreads = lambda n: None
+sys.path.insert(0, {REF!r}); sys.path.insert(0, {ROOT!r}); logging.disable(logging.CRITICAL)
+import msod_amd
+from msod_amd.models.configs import named_config
+from models.yolo_test import Model
+m = Model(named_config("cfg2")).half()
+torch.save({{"model": m, "ema": None, "epoch": 3}}, {str(ck)!r})
+"""
+    subprocess.run([sys.executable, "-c", script], check=True, capture_output=True)
+    from msod_amd import compat
+    model = compat.attempt_load(str(ck), map_location="cpu")
+    assert type(model).__module__.startswith("msod_amd") and model.compute_dtype == torch.bfloat16
+    assert type(model.model[-1]).__name__ == "Detect" and not hasattr(model.model[1], "bn")     # fused
+    assert all(p.dtype == torch.float32 for p in model.parameters())
+    ups = [m for m in model.model if isinstance(m, torch.nn.Upsample)]
+    assert len(ups) == 2 and all(type(u).__module__.startswith("msod_amd") for u in ups)
+    for name in ("models", "models.common", "models.yolo_test"):
+        sys.modules.pop(name, None)
