@@ -18,7 +18,9 @@
 //                  applied on the SOURCE side: lane (row r, slot s) fetches k-granule s ^ (r & 7).
 //                  Masked granules (image border, K tail, N tail) fetch from a zero page.
 //     GLDS = false global -> VGPR -> ds_write_b128 (register staging, loads issued one K step ahead)
-//   Double-buffered, one barrier per K step.
+//   Double-buffered, one barrier per K step.  (Deeper vmcnt-counted rings, 32x32 MFMA with swapped
+//   operands + permlane epilogue and a register-double-buffered 8-wave variant were built and measured
+//   slower on MI355X - see profiles/r01_gemm_experiments.md - and are not part of the library.)
 //   bf16: v_mfma_f32_16x16x32_bf16 (lane holds 8 consecutive k of one row = one granule);
 //   f32 : 4 x v_mfma_f32_16x16x4_f32 per granule (exact fp32 products, fp32 accumulate).
 //   Both operands use the same (lane-group, element) -> k assignment, so the reduction is a
@@ -161,7 +163,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc
   }
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS>
+// ABLATE (tuning only): 0 = normal; 1 = no global loads after the first tile (compute-only bound);
+// 2 = no MFMA (staging-only bound); 3 = neither (barrier / address-math skeleton).
+template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvParams p) {
   constexpr int NTHR = 64 * WGM * WGN;
   constexpr int GE = Elem<T>::GE;
@@ -276,7 +280,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
   const int lrow = lane & 15, lgrp = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) CFT_LOAD_TILE(kt + 1, buf ^ 1)
+    if (kt + 1 < nk && !(ABLATE & 1)) CFT_LOAD_TILE(kt + 1, buf ^ 1)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kg = ks * 4 + lgrp;
@@ -294,7 +298,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = mma_granule<T>(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < NT; ++j) {
+          if constexpr (ABLATE & 2) { asm volatile("" ::"v"(af[i]), "v"(bf[j])); }
+          else acc[i][j] = mma_granule<T>(af[i], bf[j], acc[i][j]);
+        }
     }
     if (kt + 1 < nk) CFT_STORE_TILE(buf ^ 1)
     __syncthreads();
@@ -302,144 +309,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
 #undef CFT_LOAD_TILE
 #undef CFT_STORE_TILE
 
-  conv_epilogue<WM, WN>(p, acc, smem, m0, n0, wm, wn, wave, lane);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Pipelined variant: STAGES-deep ring of LDS stages filled by global_load_lds, counted vmcnt and raw
-// s_barrier so that STAGES-1 K steps of loads stay in flight across the barriers (a __syncthreads()
-// would drain them: it carries vmcnt(0) while an LDS-DMA is pending).  Per K step:
-//     s_waitcnt vmcnt(own loads of later tiles)   -> this wave's part of tile kt has landed
-//     s_barrier                                   -> everybody's part has; stage (kt-1)%S is free
-//     issue loads of tile kt+S-1 into that stage
-//     MFMA on stage kt%S
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES>
-__global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_pipe_kernel(const ConvParams p) {
-  constexpr int NTHR = 64 * WGM * WGN;
-  constexpr int GE = Elem<T>::GE;
-  constexpr int BK = 8 * GE;
-  constexpr int RPP = NTHR / 8;
-  constexpr int A_PER = BM / RPP, B_PER = BN / RPP, LPT = A_PER + B_PER;
-  constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 16, NT = WN / 16;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int ES = (int)sizeof(T);
-  static_assert(BM % RPP == 0 && BN % RPP == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
-  static_assert(STAGES >= 2 && STAGES <= 4 && LPT * (STAGES - 2) < 64, "pipeline depth");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int nb = gridDim.x, bid = blockIdx.x;
-  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, slot = bid >> 3;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  const int tm = logical / p.tilesN, tn = logical - tm * p.tilesN;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave - wm * WGN;
-  const int r0 = tid >> 3;
-  const int g = (tid & 7) ^ (r0 & 7);   // source-side swizzle: slot s of row r holds k-granule s ^ (r & 7)
-
-  const unsigned char* a_ptr[A_PER];
-  uint32_t a_mask[A_PER];
-#pragma unroll
-  for (int i = 0; i < A_PER; ++i) {
-    const int m = m0 + r0 + i * RPP;
-    a_ptr[i] = p.x;
-    a_mask[i] = 0;
-    if (m < p.M) {
-      const int t = fast_div(m, p.wo_mul, p.wo_sh);
-      const int wo = m - t * p.Wo;
-      const int b = fast_div(t, p.ho_mul, p.ho_sh);
-      const int ho = t - b * p.Ho;
-      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-      a_ptr[i] = p.x + ((long)((b * p.H + hi0) * p.W + wi0) * p.ldx + p.xoff) * ES;
-      uint32_t wbits = 0, mk = 0;   // tap validity = (row kh in image) x (column kw in image)
-      for (int kw = 0; kw < p.KS; ++kw) wbits |= ((unsigned)(wi0 + kw) < (unsigned)p.W ? 1u : 0u) << kw;
-      for (int kh = 0; kh < p.KS; ++kh)
-        if ((unsigned)(hi0 + kh) < (unsigned)p.H) mk |= wbits << (kh * p.KS);
-      a_mask[i] = mk;
-    }
-  }
-  const unsigned char* b_ptr[B_PER];
-#pragma unroll
-  for (int i = 0; i < B_PER; ++i) {
-    const int n = n0 + r0 + i * RPP;
-    b_ptr[i] = (n < p.N) ? p.w + ((long)n * p.Kpad + g * GE) * ES : nullptr;
-  }
-  int ci = g * GE, kh = 0, kw = 0, tap = 0;
-  while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }
-  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(cft_zero_page);
-
-#define CFT_ISSUE_TILE(kt_, st_)                                                                       \
-  {                                                                                                    \
-    const bool kin = ((kt_) * BK + g * GE) < p.K;                                                      \
-    const long tapoff = (((long)kh * p.W + kw) * p.ldx + ci) * ES;                                     \
-    unsigned char* stg = smem + (st_) * STAGE_BYTES + wave * 1024;                                     \
-    _Pragma("unroll") for (int i = 0; i < A_PER; ++i) {                                                \
-      const bool v = kin && ((a_mask[i] >> tap) & 1u);                                                 \
-      const unsigned char* src = v ? a_ptr[i] + tapoff : zero_page;                                    \
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stg + i * (RPP * 128)), 16, 0, 0); \
-    }                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < B_PER; ++i) {                                                \
-      const unsigned char* src = b_ptr[i] ? b_ptr[i] + (long)(kt_) * (BK * ES) : zero_page;            \
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stg + A_BYTES + i * (RPP * 128)), 16, 0, 0); \
-    }                                                                                                  \
-    ci += BK;                                                                                          \
-    while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }                    \
-  }
-
-  f32x4_t acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.Kpad / BK;
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) CFT_ISSUE_TILE(s, s)
-
-  const int lrow = lane & 15, lgrp = lane >> 4;
-  int st = 0;                 // stage holding tile kt
-  int st_free = STAGES - 1;   // stage that tile kt+STAGES-1 goes to
-  for (int kt = 0; kt < nk; ++kt) {
-    const int later = nk - 1 - kt;   // tiles after kt that exist; min(later, STAGES-2) of them are already issued
-    if (STAGES >= 4 && later >= 2) wait_vmcnt<(STAGES >= 4 ? 2 : 0) * LPT>();
-    else if (STAGES >= 3 && later >= 1) wait_vmcnt<(STAGES >= 3 ? 1 : 0) * LPT>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + STAGES - 1 < nk) CFT_ISSUE_TILE(kt + STAGES - 1, st_free)
-    const unsigned char* sA = smem + st * STAGE_BYTES;
-    const unsigned char* sB = sA + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kg = ks * 4 + lgrp;
-      gran_t af[MT], bf[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = wm * WM + i * 16 + lrow;
-        af[i] = *reinterpret_cast<const gran_t*>(sA + row * 128 + ((kg ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int row = wn * WN + j * 16 + lrow;
-        bf[j] = *reinterpret_cast<const gran_t*>(sB + row * 128 + ((kg ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = mma_granule<T>(af[i], bf[j], acc[i][j]);
-    }
-    st_free = st;
-    st = (st + 1 == STAGES) ? 0 : st + 1;
-  }
-#undef CFT_ISSUE_TILE
-  __syncthreads();   // all waves are done reading the stages the epilogue strips alias
   conv_epilogue<WM, WN>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
@@ -462,76 +331,39 @@ extern "C" int cft_set_conv_variant(int v) {
   return old;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS>
+template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
   constexpr int smem_bytes = 2 * (BM + BN) * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     attr_done = true;
   }
   ConvParams q = p;
   const int tilesM = (p.M + BM - 1) / BM;
   q.tilesN = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS>), dim3(tilesM * q.tilesN), dim3(64 * WGM * WGN), smem_bytes, stream, q);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE>), dim3(tilesM * q.tilesN), dim3(64 * WGM * WGN), smem_bytes, stream, q);
   return cft_check_launch("conv_gemm_kernel");
-}
-
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES>
-static int launch_pipe(const ConvParams& p, hipStream_t stream) {
-  constexpr int smem_bytes = STAGES * (BM + BN) * 128;
-  static_assert(smem_bytes <= 160 * 1024, "LDS budget");
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_pipe_kernel<T, BM, BN, WGM, WGN, STAGES>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    attr_done = true;
-  }
-  ConvParams q = p;
-  const int tilesM = (p.M + BM - 1) / BM;
-  q.tilesN = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((conv_gemm_pipe_kernel<T, BM, BN, WGM, WGN, STAGES>), dim3(tilesM * q.tilesN), dim3(64 * WGM * WGN), smem_bytes, stream, q);
-  return cft_check_launch("conv_gemm_pipe_kernel");
 }
 
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
-  switch (g_conv_variant) {
-    case 10: return launch_pipe<T, 256, 128, 4, 2, 3>(p, stream);
-    case 11: return launch_pipe<T, 128, 128, 2, 2, 3>(p, stream);
-    case 12: return launch_pipe<T, 128, 128, 2, 2, 2>(p, stream);
-    case 13: return launch_pipe<T, 256, 64, 4, 2, 3>(p, stream);
-    case 14: return launch_pipe<T, 256, 64, 4, 2, 4>(p, stream);
-    case 15: return launch_pipe<T, 128, 64, 2, 2, 3>(p, stream);
-    case 16: return launch_pipe<T, 128, 64, 2, 2, 4>(p, stream);
-    case 17: return launch_pipe<T, 256, 128, 4, 2, 2>(p, stream);
-    case 18: return launch_pipe<T, 128, 256, 2, 4, 3>(p, stream);
-    case 19: return launch_pipe<T, 128, 128, 2, 2, 4>(p, stream);
-    case 20: return launch_pipe<T, 256, 128, 2, 2, 3>(p, stream);
-    case 21: return launch_pipe<T, 256, 256, 2, 4, 2>(p, stream);
-    case 1: return launch_conv<T, 128, 128, 2, 2, false>(p, stream);
+  switch (g_conv_variant) {   // forced configurations (tools/gemm_bench.py, tests); 1xx/2xx/3xx = ablations of xx
+    case 1: return launch_conv<T, 128, 128, 2, 2, false>(p, stream);   // register-staged baseline
     case 2: return launch_conv<T, 128, 128, 2, 2, true>(p, stream);
-    case 3: return launch_conv<T, 128, 64, 2, 2, false>(p, stream);
     case 4: return launch_conv<T, 128, 64, 2, 2, true>(p, stream);
-    case 5: return launch_conv<T, 256, 128, 4, 2, true>(p, stream);
     case 6: return launch_conv<T, 256, 64, 4, 2, true>(p, stream);
     case 7: return launch_conv<T, 64, 128, 2, 2, true>(p, stream);
     case 8: return launch_conv<T, 64, 64, 2, 2, true>(p, stream);
-    case 9: return launch_conv<T, 128, 256, 2, 4, true>(p, stream);
-    case 22: return launch_conv<T, 128, 128, 4, 2, true>(p, stream);
     case 23: return launch_conv<T, 128, 128, 2, 4, true>(p, stream);
-    case 24: return launch_conv<T, 256, 128, 4, 4, true>(p, stream);
-    case 25: return launch_conv<T, 256, 128, 8, 2, true>(p, stream);
-    case 26: return launch_conv<T, 128, 64, 4, 2, true>(p, stream);
     case 27: return launch_conv<T, 256, 256, 4, 4, true>(p, stream);
-    case 29: return launch_conv<T, 128, 256, 4, 4, true>(p, stream);
     case 30: return launch_conv<T, 512, 128, 8, 2, true>(p, stream);
-    case 31: return launch_conv<T, 256, 256, 2, 4, true>(p, stream);
     case 32: return launch_conv<T, 512, 64, 8, 2, true>(p, stream);
     case 33: return launch_conv<T, 256, 128, 4, 2, true>(p, stream);
-    case 34: return launch_conv<T, 256, 64, 4, 4, true>(p, stream);
-    case 35: return launch_conv<T, 128, 64, 4, 1, true>(p, stream);
+    case 127: return launch_conv<T, 256, 256, 4, 4, true, 1>(p, stream);
+    case 227: return launch_conv<T, 256, 256, 4, 4, true, 2>(p, stream);
+    case 327: return launch_conv<T, 256, 256, 4, 4, true, 3>(p, stream);
     default: break;
   }
   // Automatic choice (measured on MI355X with tools/gemm_bench.py, yolov5l+CFTx3 layer shapes, bf16):
