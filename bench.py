@@ -37,30 +37,65 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MI
 PEAK_F32_TFLOPS = 157.3
 
 
+def event_bracket_overhead(n=200):
+    """Elapsed time reported by an EMPTY event bracket on the current stream: what recording two events
+    back to back costs; subtracted from every bracketed launch (the rocprofv3 trace of the instrumented
+    forward shows exactly this gap around each kernel)."""
+    pairs = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in pairs)
+    return ts[len(ts) // 2] * 1e-3
+
+
 def gemm_family_time(model, rgb, ir):
     """One eager forward with every GEMM launch bracketed by HIP events -> per-family totals."""
+    ovh = event_bracket_overhead()
     log = []
     ops.set_launch_log(log)
+    overlap = model.overlap_streams
+    model.overlap_streams = False       # per-launch brackets are only meaningful on a single stream
     try:
         with torch.no_grad():
             model.forward_once(rgb, ir)
         torch.cuda.synchronize()
     finally:
         ops.set_launch_log(None)
+        model.overlap_streams = overlap
     fam = {}
-    for name, flops, e0, e1 in log:
+    abytes = 0.0
+    for name, flops, e0, e1, ab in log:
+        abytes += ab
         f = fam.setdefault(name, [0, 0.0, 0.0])
         f[0] += 1
         f[1] += flops
-        f[2] += e0.elapsed_time(e1) * 1e-3
+        f[2] += max(e0.elapsed_time(e1) * 1e-3 - ovh, 1e-7)
     n = sum(v[0] for v in fam.values())
     flops = sum(v[1] for v in fam.values())
     secs = sum(v[2] for v in fam.values())
-    return n, flops, secs, fam
+    return n, flops, secs, fam, ovh, abytes
 
 
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def traffic_from_profile(args, n_launch, abytes):
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh ->
+    profiles/*_traffic.json: FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, summed
+    over the conv_gemm family of one forward).  Only reported for the configuration it was collected on."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    if (t.get("config"), t.get("batch"), t.get("size"), t.get("dtype")) != (args.config, args.batch, args.size, args.dtype):
+        return None
+    return {"bytes_per_launch": t["gemm_bytes_per_forward"] / n_launch, "algorithmic_bytes_per_launch": abytes / n_launch,
+            "source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
 
 
 def cpu_baseline(cfg, sd, height, width, budget_s=20.0):
@@ -98,6 +133,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run both backbones on one HIP stream")
     args = ap.parse_args()
 
     rank, world, local = D.init_from_env()
@@ -113,6 +149,7 @@ def main():
     sd = seeded_state_dict(model.state_dict(), seed=0)      # random-init weights, BN/pos_emb non-trivial
     model.load_state_dict(sd)
     model = model.to(dev).fuse().set_compute_dtype(dtype)   # deployed form: BN folded (attempt_load does .fuse())
+    model.overlap_streams = not args.no_overlap
     rgb, ir = seeded_inputs(args.batch, args.size, args.size, seed=rank)
     rgb, ir = rgb.to(dev), ir.to(dev)
 
@@ -160,7 +197,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * args.batch * args.steps / elapsed
-        n_launch, flops, secs, fam = gemm_family_time(model, rgb, ir)
+        n_launch, flops, secs, fam, ovh, abytes = gemm_family_time(model, rgb, ir)
         log(f"gemm family: {n_launch} launches, {secs * 1e3:.2f} ms, {flops / secs / 1e12:.1f} TFLOP/s")
         top = sorted(fam.items(), key=lambda kv: -kv[1][2])[:6]
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
@@ -173,10 +210,11 @@ def main():
             "config": {"workload": f"{args.config}: yolov5l_fusion_transformerx3_FLIR_aligned two-stream forward, "
                                    f"{args.size}x{args.size}, {args.batch} pairs/GPU, BN folded, pre-NMS detections",
                        "pairs_per_gpu": args.batch, "image_size": args.size, "parallelism": f"batch-shard x{world}",
-                       "hip_graph": not args.no_graph},
+                       "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear family)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": None, "launches_per_step": n_launch,
+                         "traffic": traffic_from_profile(args, n_launch, abytes), "launches_per_step": n_launch,
+                         "event_bracket_overhead_us": round(ovh * 1e6, 2),
                          "avg_launch_us": round(secs / n_launch * 1e6, 2),
                          "flops_per_step": flops, "gemm_time_share_of_step": round(secs * 1e3 / ms, 3),
                          "top_shapes": [{"shape": k, "launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),

@@ -179,6 +179,7 @@ class Model(nn.Module):
             self._initialize_biases()
         self._graphs = {}
         self.compute_dtype = torch.bfloat16
+        self.overlap_streams = True      # run the RGB and the IR backbone on two HIP streams
         self.eval()
 
     def __setstate__(self, state):
@@ -186,6 +187,7 @@ class Model(nn.Module):
         super().__setstate__(state)
         self.__dict__.setdefault("_graphs", {})
         self.__dict__.setdefault("compute_dtype", torch.bfloat16)
+        self.__dict__.setdefault("overlap_streams", True)
 
     # ---- reference-compatible API -----------------------------------------------------------
     def forward(self, x, x2, augment=False, profile=False):
@@ -198,15 +200,65 @@ class Model(nn.Module):
             return g.replay(x, x2)
         return self.forward_once(x, x2, profile)
 
+    def stream_lanes(self):
+        """Lane (HIP stream) of every layer: the IR backbone - everything reachable from an ``f == -4``
+        entry through single-input edges, plus ``Add2(index=1)`` whose base input is the IR feature - is
+        lane 1; joins (GPT, Add, Concat, Detect) and the RGB backbone/head are lane 0."""
+        lanes = []
+        for i, m in enumerate(self.model):
+            f = m.f
+            if f == -4:
+                lane = 1
+            elif i == 0:
+                lane = 0
+            elif isinstance(f, int):
+                lane = lanes[i + f] if f < 0 else lanes[f]
+            elif isinstance(m, Add2):
+                j = f[0]
+                lane = lanes[i + j] if j < 0 else lanes[j]
+            else:
+                lane = 0
+            lanes.append(lane)
+        return lanes
+
     def forward_once(self, x, x2, profile=False):
         """Graph walk of reference models/yolo_test.py:235-272: ``f == -1`` previous output, int /
-        list = saved outputs, ``f == -4`` = this layer consumes the IR image ``x2``."""
-        y = []
-        for m in self.model:
-            if m.f != -1 and m.f != -4:
-                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
-            x = m(x2) if m.f == -4 else m(x)
+        list = saved outputs, ``f == -4`` = this layer consumes the IR image ``x2``.
+
+        The two backbones are independent between fusion points, so with ``overlap_streams`` they are
+        enqueued on two HIP streams (fork/join by stream waits; inside a HIP-graph capture this becomes
+        two parallel branches of the graph).  Every tensor that crosses lanes is a saved layer output
+        and stays referenced in ``y`` until the walk ends, so the caching allocator cannot recycle it
+        under a kernel of the other stream."""
+        lanes = self.stream_lanes() if (self.overlap_streams and x.is_cuda) else None
+        if lanes is None or 1 not in lanes:
+            y = []
+            for m in self.model:
+                if m.f != -1 and m.f != -4:
+                    x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+                x = m(x2) if m.f == -4 else m(x)
+                y.append(x if m.i in self.save else None)
+            return x
+        main = torch.cuda.current_stream(x.device)
+        side = self.__dict__.get("_side_stream")
+        if side is None or side.device != x.device:
+            side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=x.device)
+        streams = (main, side)
+        side.wait_stream(main)                       # fork: the side lane starts after everything queued so far
+        y, keep = [], []
+        for i, m in enumerate(self.model):
+            lane = lanes[i]
+            f = m.f
+            srcs = [] if (f == -4 or i == 0) else ([i - 1] if f == -1 else ([f % i] if isinstance(f, int) else [(i - 1 if j == -1 else j % i) for j in f]))
+            if any(lanes[j] != lane for j in srcs):
+                streams[lane].wait_stream(streams[1 - lane])
+            if f != -1 and f != -4:
+                x = y[f] if isinstance(f, int) else [x if j == -1 else y[j] for j in f]
+            with torch.cuda.stream(streams[lane]):
+                x = m(x2) if f == -4 else m(x)
+            keep.append(x)                           # keep every output alive until both lanes have joined
             y.append(x if m.i in self.save else None)
+        main.wait_stream(side)                       # join
         return x
 
     def _initialize_biases(self, cf=None):  # reference :274-282

@@ -127,14 +127,14 @@ def set_launch_log(log):
     _launch_log = log
 
 
-def _timed_gemm(lib, rows, pk, args):
+def _timed_gemm(lib, rows, pk, args, abytes=0.0):
     if _launch_log is None:
         return lib.cft_conv2d(*args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     st = lib.cft_conv2d(*args)
     e1.record()
-    _launch_log.append((f"k{pk.k}s{pk.s}_n{pk.n}_K{pk.kpad}", rows * pk.flops_per_row, e0, e1))
+    _launch_log.append((f"k{pk.k}s{pk.s}_n{pk.n}_K{pk.kpad}", rows * pk.flops_per_row, e0, e1, abytes))
     return st
 
 
@@ -160,10 +160,13 @@ def conv2d(x, pk, act, residual=None, out=None, out_dtype=None):
         ldr = _view_ld(residual, "conv2d residual")
         rp, rdt = residual.data_ptr(), _dt(residual.dtype)
     lib = _lib.load()
+    es_in, es_out = x.element_size(), out.element_size()
+    abytes = (B * H * W * pk.cin * es_in + B * Ho * Wo * pk.n_valid * es_out + pk.w.numel() * es_in
+              + (0 if residual is None else residual.numel() * residual.element_size()))
     st = _timed_gemm(lib, B * Ho * Wo, pk,
                      (x.data_ptr(), pk.w.data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None, rp,
                       out.data_ptr(), B, H, W, pk.cin, ldx, 0, pk.n, pk.kpad, pk.k, pk.s,
-                      ldy, 0, ldr, 0, act, _dt(x.dtype), _dt(out.dtype), rdt, _stream()))
+                      ldy, 0, ldr, 0, act, _dt(x.dtype), _dt(out.dtype), rdt, _stream()), abytes)
     _lib.check(st, "cft_conv2d")
     return out
 
@@ -180,10 +183,12 @@ def linear(x, pk, act=ACT_NONE, residual=None, out=None, out_dtype=None):
     if residual is not None:
         rp, ldr, rdt = residual.data_ptr(), residual.stride(0), _dt(residual.dtype)
     lib = _lib.load()
+    abytes = (rows * K * x.element_size() + rows * pk.n_valid * out.element_size() + pk.w.numel() * x.element_size()
+              + (0 if residual is None else rows * pk.n_valid * residual.element_size()))
     st = _timed_gemm(lib, rows, pk,
                      (x.data_ptr(), pk.w.data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None, rp,
                       out.data_ptr(), 1, 1, rows, pk.cin, x.stride(0), 0, pk.n, pk.kpad, 1, 1,
-                      out.stride(0), 0, ldr, 0, act, _dt(x.dtype), _dt(out.dtype), rdt, _stream()))
+                      out.stride(0), 0, ldr, 0, act, _dt(x.dtype), _dt(out.dtype), rdt, _stream()), abytes)
     _lib.check(st, "cft_conv2d(linear)")
     return out
 

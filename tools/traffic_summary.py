@@ -1,0 +1,35 @@
+"""Reduce the PMC passes of tools/pmc_traffic.sh to profiles/r01_traffic.json (bytes per forward per kernel)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root, out = sys.argv[1], sys.argv[2]
+meta = dict(a.split("=") for a in sys.argv[3:])
+tot = {"FETCH_SIZE": defaultdict(float), "WRITE_SIZE": defaultdict(float)}
+calls = defaultdict(int)
+for c in tot:
+    for f in glob.glob(os.path.join(root, c, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != c:
+                continue
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            tot[c][k] += float(row["Counter_Value"]) * 1024.0        # counters are in KiB
+            if c == "FETCH_SIZE":
+                calls[k] += 1
+focus = [k for k in calls if "focus_s2d" in k]
+n_fwd = calls[focus[0]] / 2 if focus else 1          # two Focus launches per forward
+kern = {}
+for k in sorted(calls, key=lambda k: -(2 * tot["FETCH_SIZE"][k] + tot["WRITE_SIZE"][k])):
+    kern[k] = {"launches_per_forward": calls[k] / n_fwd,
+               "hbm_read_bytes": 2.0 * tot["FETCH_SIZE"][k] / n_fwd,     # gfx950: FETCH_SIZE counts 64 B per 128-B request
+               "hbm_write_bytes": tot["WRITE_SIZE"][k] / n_fwd}
+gemm = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for k, v in kern.items() if "conv_gemm" in k)
+allb = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in kern.values())
+res = {"config": meta.get("config", "cfg3"), "batch": int(meta.get("batch", 64)), "size": int(meta.get("size", 640)),
+       "dtype": meta.get("dtype", "bf16"), "forwards_profiled": n_fwd, "gemm_bytes_per_forward": gemm,
+       "all_kernels_bytes_per_forward": allb, "kernels": kern}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps({k: res[k] for k in ("forwards_profiled", "gemm_bytes_per_forward", "all_kernels_bytes_per_forward")}))
