@@ -33,6 +33,9 @@ from msod_amd.models.configs import named_config  # noqa: E402
 from msod_amd.models.yolo_test import Model  # noqa: E402
 from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict  # noqa: E402
 
+WORKLOADS = {"cfg1": "yolov5s add-fusion, no CFT", "cfg2": "yolov5s + 1 CFT block",
+             "cfg3": "yolov5l_fusion_transformerx3_FLIR_aligned", "cfg4": "yolov5l_fusion_transformerx3_llvip",
+             "cfg5": "yolov5x x3 CFT (derived)"}
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 
@@ -207,7 +210,7 @@ def main():
             "value": round(value, 2), "unit": "image-pairs/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.config}: yolov5l_fusion_transformerx3_FLIR_aligned two-stream forward, "
+            "config": {"workload": f"{args.config} ({WORKLOADS.get(args.config, args.config)}) two-stream forward, "
                                    f"{args.size}x{args.size}, {args.batch} pairs/GPU, BN folded, pre-NMS detections",
                        "pairs_per_gpu": args.batch, "image_size": args.size, "parallelism": f"batch-shard x{world}",
                        "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap},

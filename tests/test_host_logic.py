@@ -165,3 +165,17 @@ torch.save({{"model": m, "ema": None, "epoch": 3}}, {str(ck)!r})
     assert len(ups) == 2 and all(type(u).__module__.startswith("msod_amd") for u in ups)
     for name in ("models", "models.common", "models.yolo_test"):
         sys.modules.pop(name, None)
+
+
+def test_stream_lanes_follow_the_ir_backbone():
+    """Two-HIP-stream schedule: the IR backbone (everything downstream of an ``f == -4`` entry through
+    single-input edges, plus Add2(index=1)) is lane 1; joins and the RGB backbone/head are lane 0."""
+    m = Model(configs.named_config("cfg3"))
+    lanes = m.stream_lanes()
+    assert len(lanes) == 47
+    assert [i for i, l in enumerate(lanes) if l == 1] == [5, 6, 7, 8, 9, 12, 15, 16, 19, 23, 24, 25, 28]
+    for i, mod in enumerate(m.model):
+        if type(mod).__name__ in ("GPT", "Add", "Concat", "Detect"):
+            assert lanes[i] == 0
+    add = Model(configs.named_config("cfg1")).stream_lanes()
+    assert add[:10] == [0] * 10 and add[10:20] == [1] * 10 and set(add[20:]) == {0}
