@@ -15,7 +15,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcft_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("runtime.hip", "conv_gemm.hip", "pointwise.hip", "attention.hip")
+SOURCES = ("runtime.hip", "conv_gemm.hip", "pointwise.hip", "attention.hip", "nms.hip")
 
 CFT_BF16, CFT_F32 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
@@ -37,6 +37,7 @@ SIGNATURES = {
     "cft_layernorm": [_vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp],
     "cft_attention": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cft_gpt_upsample_add": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_nms": [_vp, _i, _i, _i, _f, _f, _i, _i, _c.c_ulonglong, _i, _vp, _l, _vp, _vp, _vp],
     "cft_detect_decode": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _l, _vp],
 }
 

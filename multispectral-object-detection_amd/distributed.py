@@ -77,3 +77,15 @@ def sharded_forward(model, rgb, ir, rank, world, group=None):
     """Run ``model`` on this rank's shard of the global batch and gather every rank's detections."""
     pred, _ = model(shard_batch(rgb, rank, world), shard_batch(ir, rank, world))
     return all_gather_detections(pred, world, group)
+
+
+def sharded_detect(model, rgb, ir, rank, world, nms, group=None):
+    """Forward + on-device NMS on this rank's shard, then gather only the survivors: the collective moves
+    [B_local, max_det, 6] + counts (0.46 MB per rank at 64 pairs) instead of the 25200-row prediction tensor
+    (51.6 MB) - SURVEY.md section 8f rank 1.  ``nms(pred) -> (dets, counts)`` is
+    ``utils.general.batched_nms`` (or a partial of it).  Returns (dets [B, max_det, 6], counts [B]) on all ranks."""
+    pred, _ = model(shard_batch(rgb, rank, world), shard_batch(ir, rank, world))
+    dets, counts = nms(pred)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return dets, counts
+    return all_gather_detections(dets, world, group), all_gather_detections(counts.view(-1, 1).to(torch.float32), world, group).view(-1).to(counts.dtype)

@@ -1,0 +1,62 @@
+"""Post-processing that sits directly behind the forward in every reference caller
+(`test.py:129`, `detect_twostream.py:86`): `non_max_suppression` of the reference's
+`utils/general.py:455-543`, as ONE batched HIP kernel instead of a Python loop over images around
+`torchvision.ops.nms`."""
+import torch
+
+from .. import _lib
+from ..ops import _require_cuda, _stream
+
+MAX_WH = 4096  # class offset in pixels (reference utils/general.py:467)
+
+
+def _class_mask(classes):
+    if classes is None:
+        return (1 << 64) - 1
+    m = 0
+    for c in classes:
+        if int(c) < 64:
+            m |= 1 << int(c)
+    return m
+
+
+def batched_nms(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300):
+    """prediction [B, rows, nc+5] (fp32, on the GPU) -> (dets [B, max_det, 6] = (x1,y1,x2,y2,conf,cls),
+    counts [B] int32).  No host synchronisation: fit for HIP-graph capture and for all-gathering the
+    <= max_det survivors instead of all rows."""
+    _require_cuda(prediction, "batched_nms")
+    if prediction.dtype != torch.float32 or not prediction.is_contiguous():
+        prediction = prediction.float().contiguous()
+    B, rows, no = prediction.shape
+    nc = no - 5
+    multi_label = bool(multi_label) and nc > 1            # reference :472
+    cap = rows * (nc if multi_label else 1)
+    scratch = torch.empty((B * cap * 32,), dtype=torch.uint8, device=prediction.device)
+    dets = torch.zeros((B, max_det, 6), dtype=torch.float32, device=prediction.device)
+    counts = torch.zeros((B,), dtype=torch.int32, device=prediction.device)
+    st = _lib.load().cft_nms(prediction.data_ptr(), B, rows, no, float(conf_thres), float(iou_thres), int(bool(agnostic)),
+                             int(multi_label), _class_mask(classes), int(max_det), scratch.data_ptr(), scratch.numel(),
+                             dets.data_ptr(), counts.data_ptr(), _stream())
+    _lib.check(st, "cft_nms")
+    return dets, counts
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                        labels=()):
+    """Same signature and return value as the reference: a list with one (n,6) tensor [xyxy, conf, cls] per
+    image, sorted by descending confidence, n <= 300."""
+    if labels:
+        raise NotImplementedError("autolabelling a-priori labels (reference :480-487) are not supported")
+    dets, counts = batched_nms(prediction, conf_thres, iou_thres, classes, agnostic, multi_label)
+    counts = counts.tolist()
+    return [dets[i, :n] for i, n in enumerate(counts)]
+
+
+def xywh2xyxy(x):
+    """[x, y, w, h] -> [x1, y1, x2, y2] (reference utils/general.py:386-393); tiny, used by callers on results."""
+    y = x.clone()
+    y[..., 0] = x[..., 0] - x[..., 2] / 2
+    y[..., 1] = x[..., 1] - x[..., 3] / 2
+    y[..., 2] = x[..., 0] + x[..., 2] / 2
+    y[..., 3] = x[..., 1] + x[..., 3] / 2
+    return y

@@ -89,5 +89,32 @@ def main():
         print(f"{name:18s} pred {tuple(pred.shape)} raw std {raw[0].std():.3f} -> {os.path.getsize(path)/1e3:.0f} kB")
 
 
+def make_nms_golden():
+    """Reference `utils.general.non_max_suppression` on golden predictions.  torchvision is absent here, so
+    its one call (`torchvision.ops.nms`, utils/general.py:527) is bound to the restatement of its published
+    algorithm in oracle/nms_oracle.py; every other line executed is the reference's."""
+    install_reference()
+    sys.path.insert(0, ROOT)
+    from oracle.nms_oracle import greedy_nms
+    sys.modules["torchvision"].ops = types.SimpleNamespace(nms=greedy_nms)
+    from utils.general import non_max_suppression  # the reference
+    cases = []
+    for src, kw in [("s_x3_rect", dict(conf_thres=0.25, iou_thres=0.45)),
+                    ("s_x3_rect", dict(conf_thres=0.05, iou_thres=0.6, multi_label=True)),
+                    ("s_x3_rect", dict(conf_thres=0.3, iou_thres=0.45, agnostic=True)),
+                    ("s_x3_rect", dict(conf_thres=0.25, iou_thres=0.45, classes=[1, 4, 7])),
+                    ("l_x3_llvip_192", dict(conf_thres=0.25, iou_thres=0.45, multi_label=True)),   # nc = 1
+                    ("l_x3_flir_256", dict(conf_thres=0.9, iou_thres=0.45))]:                      # few / no survivors
+        pred = torch.load(os.path.join(HERE, src + ".pt"), weights_only=False)["pred"]
+        out = non_max_suppression(pred.clone(), **kw)
+        cases.append({"source": src, "kwargs": kw, "out": [o.clone() for o in out]})
+        print("nms", src, kw, [tuple(o.shape) for o in out])
+    torch.save(cases, os.path.join(HERE, "nms_cases.pt"))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "nms":
+        make_nms_golden()
+    else:
+        main()
+        make_nms_golden()
