@@ -74,6 +74,15 @@ int cft_set_conv_variant(int variant);
 int cft_focus_s2d(const float* in, void* out, int B, int H, int W, int dtype, void* stream);
 
 /*
+ * Same, for the uint8 images the reference's callers hold (one [B,6,H,W] uint8 tensor: RGB = channels 0-2,
+ * IR = 3-5; test.py:106-113 does `.float()/255` and the split before calling the model).  `in` points at the
+ * first channel of the stream, element strides in bytes for batch / channel / row (row elements contiguous);
+ * out[...] = in[...] * scale (scale = 1/255).
+ */
+int cft_focus_s2d_u8(const unsigned char* in, long stride_b, long stride_c, long stride_h, void* out,
+                     int B, int H, int W, float scale, int dtype, void* stream);
+
+/*
  * SPP max pools (models/common.py:161-165): reads channels [0,C) of the NHWC buffer `buf`
  * (ld channels/pixel) and writes max_pool2d(k, stride 1, pad k/2) for k = k1,k2,k3 to channel
  * slices [C,2C), [2C,3C), [3C,4C) of the same buffer.  k odd, <= 13, k1 <= k2 <= k3.

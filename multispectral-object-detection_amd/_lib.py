@@ -30,6 +30,7 @@ SIGNATURES = {
     "cft_conv2d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_set_conv_variant": [_i],
     "cft_focus_s2d": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "cft_focus_s2d_u8": [_vp, _l, _l, _l, _vp, _i, _i, _i, _f, _i, _vp],
     "cft_spp_maxpool": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_copy_channels": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_add": [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _l, _i, _i, _vp],

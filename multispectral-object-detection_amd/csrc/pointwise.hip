@@ -55,6 +55,52 @@ extern "C" int cft_focus_s2d(const float* in, void* out, int B, int H, int W, in
   return cft_check_launch("focus_s2d_kernel");
 }
 
+// uint8 variant: the reference's callers hold the pair as ONE uint8 [B,6,H,W] tensor and do
+// `img.float() / 255` then `img[:, :3]` / `img[:, 3:]` on the host side of the model (test.py:106-113,
+// detect_twostream.py:69-79).  Here the normalisation, the channel split (via strides) and the cast are folded
+// into the space-to-depth gather: 4x less input traffic, no fp32 image copy at all.
+template <typename T>
+__global__ void __launch_bounds__(256) focus_s2d_u8_kernel(const unsigned char* __restrict__ in, long sb, long sc, long sh,
+                                                           unsigned char* __restrict__ out, int B, int H, int W, float scale) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long total = (long)B * Ho * Wo;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % Wo);
+    const long t = idx / Wo;
+    const int y = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const unsigned char* base = in + (long)b * sb + (long)c * sc + (long)(2 * y) * sh + 2 * x;
+      v[0 + c] = (float)base[0] * scale;        // (dy=0, dx=0)
+      v[6 + c] = (float)base[1] * scale;        // (dy=0, dx=1)
+      v[3 + c] = (float)base[sh] * scale;       // (dy=1, dx=0)
+      v[9 + c] = (float)base[sh + 1] * scale;   // (dy=1, dx=1)
+    }
+    v[12] = v[13] = v[14] = v[15] = 0.f;
+    constexpr int GE = Elem<T>::GE;
+    gran_t* o = reinterpret_cast<gran_t*>(out + idx * 16 * sizeof(T));
+#pragma unroll
+    for (int k = 0; k < 16 / GE; ++k) o[k] = Elem<T>::pack(v + k * GE);
+  }
+}
+
+extern "C" int cft_focus_s2d_u8(const unsigned char* in, long stride_b, long stride_c, long stride_h, void* out,
+                                int B, int H, int W, float scale, int dtype, void* stream) {
+  CFT_REQUIRE(in && out, "cft_focus_s2d_u8: null pointer");
+  CFT_REQUIRE(B > 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0), "cft_focus_s2d_u8: H and W must be even");
+  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_focus_s2d_u8: bad dtype");
+  CFT_REQUIRE(stride_h >= W && stride_c > 0 && stride_b > 0, "cft_focus_s2d_u8: bad strides");
+  const long total = (long)B * (H / 2) * (W / 2);
+  const int grid = grid_for(total, 256);
+  if (dtype == CFT_BF16)
+    hipLaunchKernelGGL(focus_s2d_u8_kernel<uint16_t>, dim3(grid), dim3(256), 0, as_stream(stream), in, stride_b, stride_c, stride_h, (unsigned char*)out, B, H, W, scale);
+  else
+    hipLaunchKernelGGL(focus_s2d_u8_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), in, stride_b, stride_c, stride_h, (unsigned char*)out, B, H, W, scale);
+  return cft_check_launch("focus_s2d_u8_kernel");
+}
+
 // ------------------------------------------------------------------------------- SPP
 // One workgroup per (image, 16-byte channel granule).  The HxW plane of that granule is staged
 // in LDS, then two separable passes (row maxima for the three radii, then column maxima).

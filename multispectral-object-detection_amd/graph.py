@@ -10,11 +10,11 @@ import torch
 
 
 class CapturedForward:
-    def __init__(self, model, batch, height, width, warmup=2):
+    def __init__(self, model, batch, height, width, warmup=2, input_dtype=torch.float32):
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("capture: model must be on the GPU")
-        self.rgb = torch.zeros((batch, 3, height, width), dtype=torch.float32, device=dev)
+        self.rgb = torch.zeros((batch, 3, height, width), dtype=input_dtype, device=dev)
         self.ir = torch.zeros_like(self.rgb)
         model.prepare()
         side = torch.cuda.Stream(device=dev)

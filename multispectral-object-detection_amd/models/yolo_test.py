@@ -194,7 +194,7 @@ class Model(nn.Module):
         if augment:
             raise NotImplementedError("augmented inference is broken for two-stream models in the reference "
                                       "(models/yolo_test.py:215-230 calls forward_once with one input)")
-        key = (tuple(x.shape), self.compute_dtype)
+        key = (tuple(x.shape), self.compute_dtype, x.dtype)
         g = self._graphs.get(key)
         if g is not None:
             return g.replay(x, x2)
@@ -310,13 +310,13 @@ class Model(nn.Module):
                 m._packed(self.compute_dtype, dev)
         return self
 
-    def capture(self, batch, height, width):
+    def capture(self, batch, height, width, input_dtype=torch.float32):
         """Record the forward for a fixed input shape into a HIP graph; later ``model(x, x2)`` calls
         with that shape replay it (inputs are copied into static buffers, outputs are static
         tensors that the next replay overwrites)."""
         from ..graph import CapturedForward
-        key = ((batch, 3, height, width), self.compute_dtype)
-        self._graphs[key] = CapturedForward(self, batch, height, width)
+        key = ((batch, 3, height, width), self.compute_dtype, input_dtype)
+        self._graphs[key] = CapturedForward(self, batch, height, width, input_dtype=input_dtype)
         return self._graphs[key]
 
     def release_graphs(self):

@@ -196,6 +196,17 @@ def linear(x, pk, act=ACT_NONE, residual=None, out=None, out_dtype=None):
 def focus_s2d(img, dtype):
     """[B,3,H,W] float image batch (NCHW) -> [B,16,H/2,W/2] NHWC in ``dtype`` (12 real channels)."""
     _require_cuda(img, "focus_s2d")
+    if img.dtype == torch.uint8:
+        # raw camera bytes, e.g. ``img6[:, :3]`` / ``img6[:, 3:]`` of the reference's [B,6,H,W] uint8 batch:
+        # normalisation (/255), channel split (strides) and cast are fused into the gather
+        B, C, H, W = img.shape
+        if C != 3 or img.stride(3) != 1:
+            raise ValueError("focus_s2d: uint8 input must be [B,3,H,W] with contiguous rows")
+        out = new_nhwc(B, H // 2, W // 2, 16, dtype, img.device)
+        st = _lib.load().cft_focus_s2d_u8(img.data_ptr(), img.stride(0), img.stride(1), img.stride(2), out.data_ptr(),
+                                          B, H, W, 1.0 / 255.0, _dt(dtype), _stream())
+        _lib.check(st, "cft_focus_s2d_u8")
+        return out
     if img.dtype != torch.float32 or not img.is_contiguous():
         img = img.float().contiguous()
     B, C, H, W = img.shape

@@ -101,3 +101,18 @@ def test_pairs_are_independent_at_full_shape(dev):
     xy = full[..., :2]
     assert xy.min() > -64 and xy.max() < 640 + 64                  # decoded centres stay near the image
     assert (full[..., 4:] >= 0).all() and (full[..., 4:] <= 1).all()
+
+
+def test_uint8_pair_input_equals_float_input(dev):
+    """Caller-side pre-processing: the model accepts the uint8 RGB / IR views of the
+    reference's [B,6,H,W] batch directly; result = forward of `.float()/255` (reference test.py:106-113)."""
+    g, cfg, model, rgb, ir = load_case([p for p in GOLDEN if p.endswith("s_x3_320.pt")][0])
+    img6 = (torch.cat([rgb, ir], 1) * 255).round().to(torch.uint8)
+    model = model.to(dev).set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        d6 = img6.to(dev)
+        p8, _ = model(d6[:, :3], d6[:, 3:])
+        f = (img6.float() / 255.0).to(dev)
+        pf, _ = model(f[:, :3].contiguous(), f[:, 3:].contiguous())
+    torch.cuda.synchronize()
+    assert torch.allclose(p8.cpu(), pf.cpu(), rtol=1e-4, atol=1e-3)

@@ -285,3 +285,18 @@ def test_conv2d_every_tile_configuration(dev, dtype, variant):
     finally:
         lib.cft_set_conv_variant(0)
     assert rel_err(to_cpu_f32(y), ref) < tol(dtype), f"variant {variant}: rel err {rel_err(to_cpu_f32(y), ref):.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_focus_uint8_pair(dev, dtype):
+    """The reference's callers hold the pair as one uint8 [B,6,H,W] tensor (test.py:106-113); slicing it and
+    handing the uint8 views to Focus must equal `.float()/255` + split + the fp32 Focus path."""
+    from msod_amd import ops
+    img6 = torch.randint(0, 256, (2, 6, 32, 48), dtype=torch.uint8, generator=torch.Generator().manual_seed(40))
+    d6 = img6.to(dev)
+    ref = img6.float() / 255.0
+    for lo in (0, 3):
+        z8 = ops.focus_s2d(d6[:, lo:lo + 3], dtype)
+        zf = ops.focus_s2d(ref[:, lo:lo + 3].contiguous().to(dev), dtype)
+        torch.cuda.synchronize()
+        assert rel_err(to_cpu_f32(z8), to_cpu_f32(zf)) < (1e-6 if dtype == torch.float32 else 4e-3)
