@@ -203,6 +203,10 @@ def main():
         n_launch, flops, secs, fam, ovh, abytes = gemm_family_time(model, rgb, ir)
         log(f"gemm family: {n_launch} launches, {secs * 1e3:.2f} ms, {flops / secs / 1e12:.1f} TFLOP/s")
         top = sorted(fam.items(), key=lambda kv: -kv[1][2])[:6]
+        if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            with open(os.path.join(ROOT, "gpurun_out", "bench_families.json"), "w") as fh:
+                json.dump({k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3, "tflops": v[1] / v[2] / 1e12}
+                           for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])}, fh, indent=1)
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
         achieved = flops / secs / 1e12
         line = {
