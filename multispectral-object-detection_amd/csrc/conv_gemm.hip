@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
   }
   int ci = g * GE, kh = 0, kw = 0, tap = 0;
   while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }
+  const bool wide_cin = p.Cin >= BK;   // uniform
 
   gran_t ra[GLDS ? 1 : A_PER], rb[GLDS ? 1 : B_PER];
   const int swz = (slot_s ^ (r0 & 7)) << 4;              // register path: where this thread's granule lands
@@ -256,7 +257,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
       }                                                                                                \
     }                                                                                                  \
     ci += BK;                                                                                          \
-    while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }                    \
+    if (wide_cin) { /* Cin >= K step: at most one tap boundary per step, branch-free */                \
+      const bool wrap = ci >= p.Cin;                                                                   \
+      ci -= wrap ? p.Cin : 0;                                                                          \
+      tap += wrap ? 1 : 0;                                                                             \
+      kw += wrap ? 1 : 0;                                                                              \
+      const bool roww = kw == p.KS;                                                                    \
+      kw = roww ? 0 : kw;                                                                              \
+      kh += roww ? 1 : 0;                                                                              \
+    } else {                                                                                           \
+      while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }                  \
+    }                                                                                                  \
   }
 #define CFT_STORE_TILE(buf_)                                                                           \
   if constexpr (!GLDS) {                                                                               \
