@@ -194,6 +194,12 @@ class Model(nn.Module):
         if augment:
             raise NotImplementedError("augmented inference is broken for two-stream models in the reference "
                                       "(models/yolo_test.py:215-230 calls forward_once with one input)")
+        if x.shape != x2.shape or x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"expected two [B,3,H,W] image batches of equal shape, got {tuple(x.shape)} and {tuple(x2.shape)}")
+        smax = int(self.stride.max()) if hasattr(self, "stride") else 32
+        if x.shape[2] % smax or x.shape[3] % smax:
+            raise ValueError(f"image height and width must be multiples of the largest stride ({smax}); got "
+                             f"{x.shape[2]}x{x.shape[3]} (the reference letterboxes to such sizes, utils/datasets.py:1698-1728)")
         key = (tuple(x.shape), self.compute_dtype, x.dtype)
         g = self._graphs.get(key)
         if g is not None:

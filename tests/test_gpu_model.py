@@ -116,3 +116,34 @@ def test_uint8_pair_input_equals_float_input(dev):
         pf, _ = model(f[:, :3].contiguous(), f[:, 3:].contiguous())
     torch.cuda.synchronize()
     assert torch.allclose(p8.cpu(), pf.cpu(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 96), (3, 96, 64), (5, 32, 32)], ids=["b1_rect", "b3_rect", "b5_min"])
+def test_small_odd_shapes_match_oracle(dev, shape):
+    """Batch 1 / odd batches, the smallest legal image (32x32: 1x1 P5 maps, adaptive pooling windows that
+    repeat pixels, bilinear upsampling from 8x8 DOWN to 1x1) and non-square inputs, fp32 vs the oracle."""
+    from msod_amd.models.configs import named_config
+    from msod_amd.models.yolo_test import Model
+    from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict
+    from oracle.cft_oracle import OracleModel
+    b, h, w = shape
+    cfg = named_config("yolov5s_fusion_transformerx3_vedai")
+    model = Model(cfg)
+    sd = seeded_state_dict(model.state_dict(), 21)
+    model.load_state_dict(sd)
+    rgb, ir = seeded_inputs(b, h, w, 21)
+    want_pred, want_raw = OracleModel(cfg)(sd, rgb, ir)
+    pred, raw = _run(model, rgb, ir, dev, torch.float32)
+    for a, c in zip(raw, want_raw):
+        assert a.shape == c.shape and (a - c).abs().max().item() <= 1e-3
+    assert torch.allclose(pred, want_pred, rtol=1e-3, atol=1e-3)
+
+
+def test_bad_image_sizes_raise(dev):
+    from msod_amd.models.configs import named_config
+    from msod_amd.models.yolo_test import Model
+    model = Model(named_config("cfg1")).to(dev)
+    with pytest.raises(ValueError, match="multiples of the largest stride"):
+        model(torch.zeros(1, 3, 100, 64, device=dev), torch.zeros(1, 3, 100, 64, device=dev))
+    with pytest.raises(ValueError, match="equal shape"):
+        model(torch.zeros(1, 3, 64, 64, device=dev), torch.zeros(2, 3, 64, 64, device=dev))
