@@ -168,29 +168,17 @@ def main():
             step_fn = cap.replay_static
             pred, _ = step_fn()
         # N > 1: the all-gather of step i runs on RCCL's stream while the forward of step i+1 runs on the compute
-        # stream (51.6 MB per rank per step would otherwise add ~10 % serial time).  The graph's static output is
-        # copied to one of two staging buffers first, because the next replay overwrites it.
-        stage, gathered, pending = None, None, [None, None]
-        if world > 1:
-            stage = [torch.empty_like(pred) for _ in range(2)]
-            gathered = [torch.empty((world * pred.shape[0],) + tuple(pred.shape[1:]), dtype=pred.dtype, device=dev) for _ in range(2)]
-        tick = [0]
+        # stream (51.6 MB per rank per step would otherwise add ~10 % serial time); see distributed.OverlappedGather.
+        gather = D.OverlappedGather(pred, world) if world > 1 else None
 
         def step():
             p, _ = step_fn()
-            if world > 1:
-                i = tick[0] & 1
-                tick[0] += 1
-                if pending[i] is not None:
-                    pending[i].wait()                       # buffer i is free again (compute stream waits)
-                stage[i].copy_(p, non_blocking=True)
-                pending[i] = torch.distributed.all_gather_into_tensor(gathered[i], stage[i], async_op=True)
+            if gather is not None:
+                gather.submit(p)
 
         def drain():
-            for i in range(2):
-                if pending[i] is not None:
-                    pending[i].wait()
-                    pending[i] = None
+            if gather is not None:
+                gather.drain()
 
         for _ in range(args.warmup):
             step()

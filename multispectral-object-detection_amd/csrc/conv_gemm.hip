@@ -218,6 +218,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
   }
   int ci = g * GE, kh = 0, kw = 0, tap = 0;
   while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }
+  int koff = (kh * p.W + kw) * p.ldx + ci;          // element offset of this thread's k-granule inside the pixel neighbourhood
+  const int tap_step = p.ldx - p.Cin;                // next tap in the same kernel row: +ldx, channel index restarts
+  const int row_step = (p.W - p.KS) * p.ldx;         // next kernel row: additionally skip to the next image row
   const bool wide_cin = p.Cin >= BK;   // uniform
 
   gran_t ra[GLDS ? 1 : A_PER], rb[GLDS ? 1 : B_PER];
@@ -230,16 +233,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
   {                                                                                                    \
     const int kglob = (kt_) * BK + g * GE;                                                             \
     const bool kin = kglob < p.K;                                                                      \
-    const long tapoff = ((long)kh * p.W + kw) * p.ldx + ci;                                            \
+    const int tapoff = koff;                                                                           \
     _Pragma("unroll") for (int i = 0; i < A_PER; ++i) {                                                \
       const bool v = kin && ((a_mask[i] >> tap) & 1u);                                                 \
       if constexpr (GLDS) {                                                                            \
-        const unsigned char* src = v ? p.x + ((long)a_off[i] + tapoff) * ES : zero_page;               \
+        const unsigned char* src = v ? p.x + (long)(a_off[i] + tapoff) * ES : zero_page;               \
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src,                                             \
             (lds_void_t*)(sA + (buf_) * A_BYTES + i * (RPP * 128) + wave * 1024), 16, 0, 0);           \
       } else {                                                                                         \
         gran_t t_ = {0u, 0u, 0u, 0u};                                                                  \
-        if (v) t_ = *reinterpret_cast<const gran_t*>(p.x + ((long)a_off[i] + tapoff) * ES);            \
+        if (v) t_ = *reinterpret_cast<const gran_t*>(p.x + (long)(a_off[i] + tapoff) * ES);            \
         ra[i] = t_;                                                                                    \
       }                                                                                                \
     }                                                                                                  \
@@ -257,16 +260,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
       }                                                                                                \
     }                                                                                                  \
     ci += BK;                                                                                          \
+    koff += BK;                                                                                        \
     if (wide_cin) { /* Cin >= K step: at most one tap boundary per step, branch-free */                \
       const bool wrap = ci >= p.Cin;                                                                   \
       ci -= wrap ? p.Cin : 0;                                                                          \
+      koff += wrap ? tap_step : 0;                                                                     \
       tap += wrap ? 1 : 0;                                                                             \
       kw += wrap ? 1 : 0;                                                                              \
       const bool roww = kw == p.KS;                                                                    \
       kw = roww ? 0 : kw;                                                                              \
-      kh += roww ? 1 : 0;                                                                              \
+      koff += roww ? row_step : 0;                                                                     \
     } else {                                                                                           \
-      while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }                  \
+      while (ci >= p.Cin) { ci -= p.Cin; koff += tap_step; ++tap; if (++kw == p.KS) { kw = 0; koff += row_step; } } \
     }                                                                                                  \
   }
 #define CFT_STORE_TILE(buf_)                                                                           \

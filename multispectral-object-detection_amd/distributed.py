@@ -89,3 +89,35 @@ def sharded_detect(model, rgb, ir, rank, world, nms, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return dets, counts
     return all_gather_detections(dets, world, group), all_gather_detections(counts.view(-1, 1).to(torch.float32), world, group).view(-1).to(counts.dtype)
+
+
+class OverlappedGather:
+    """Double-buffered, asynchronous all-gather of a tensor that is overwritten every step (the static output of
+    a captured HIP graph): ``submit(x)`` copies ``x`` into one of two staging buffers and launches
+    ``all_gather_into_tensor`` with ``async_op=True``, so the collective of step i runs on RCCL's stream while
+    the forward of step i+1 runs on the compute stream; a buffer is only reused after its previous collective
+    has been waited for.  ``drain()`` waits for everything in flight and returns the most recent gathered tensor."""
+
+    def __init__(self, like, world, group=None):
+        self.group = group
+        self.stage = [torch.empty_like(like) for _ in range(2)]
+        self.out = [torch.empty((world * like.shape[0],) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
+                    for _ in range(2)]
+        self.pending = [None, None]
+        self.tick = 0
+
+    def submit(self, x):
+        i = self.tick & 1
+        self.tick += 1
+        if self.pending[i] is not None:
+            self.pending[i].wait()
+        self.stage[i].copy_(x, non_blocking=True)
+        self.pending[i] = dist.all_gather_into_tensor(self.out[i], self.stage[i], group=self.group, async_op=True)
+        return self.out[i]
+
+    def drain(self):
+        for i in range(2):
+            if self.pending[i] is not None:
+                self.pending[i].wait()
+                self.pending[i] = None
+        return self.out[(self.tick - 1) & 1] if self.tick else None

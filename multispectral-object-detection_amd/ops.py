@@ -7,7 +7,6 @@ channel slice of a wider buffer (stride(3) = channels per pixel of the parent).
 
 No CPU path exists: CPU tensors raise.
 """
-import math
 from dataclasses import dataclass
 from typing import Optional
 
@@ -310,6 +309,3 @@ def detect_decode(logits, raw, pred, anchors_px, na, no, stride, row0):
                                        B, ny, nx, na, no, float(stride), row0, pred.shape[1], _stream())
     _lib.check(st, "cft_detect_decode")
 
-
-def attention_scale(dk):
-    return 1.0 / math.sqrt(dk)

@@ -36,6 +36,18 @@ def _worker(rank, world, port, n_pairs, q):
     dets, counts = D.sharded_detect(fake_model, rgb, ir, rank, world, fake_nms)
     fd, fc = fake_nms(full)
     ok = ok and torch.equal(dets, fd) and torch.equal(counts, fc)
+    # the bench's overlapped gather: the source tensor is overwritten every step, results must still be per-step
+    src = torch.zeros(2, 3)
+    og = D.OverlappedGather(src, world)
+    outs = []
+    for step in range(5):
+        src.fill_(10.0 * step + rank)
+        outs.append((step, og.submit(src)))
+        if step >= 1:                      # result of the previous step must be intact once its buffer is drained later
+            pass
+    last = og.drain()
+    ok = ok and torch.equal(last, torch.cat([torch.full((2, 3), 40.0 + r) for r in range(world)]))
+    ok = ok and torch.equal(outs[3][1], torch.cat([torch.full((2, 3), 30.0 + r) for r in range(world)]))
     same = D.gather_equal(torch.full((2, 3, 4), float(rank)))
     ok = ok and torch.equal(same, torch.cat([torch.full((2, 3, 4), 0.0), torch.full((2, 3, 4), 1.0)]))
     q.put((rank, ok, tuple(out.shape)))
