@@ -147,3 +147,26 @@ def test_bad_image_sizes_raise(dev):
         model(torch.zeros(1, 3, 100, 64, device=dev), torch.zeros(1, 3, 100, 64, device=dev))
     with pytest.raises(ValueError, match="equal shape"):
         model(torch.zeros(1, 3, 64, 64, device=dev), torch.zeros(2, 3, 64, 64, device=dev))
+
+
+def test_yolov5x_four_cft_blocks_matches_oracle(dev):
+    """Reference yaml `yolov5x_fusion_transformer_FLIR` (depth 1.33 / width 1.25, FOUR GPT blocks): channel counts
+    80/160/320/640/1280 exercise K steps that straddle taps, N tails (160, 320 are not multiples of the 128/256
+    tiles) and zero-padded attention heads (d=160 -> head width 20 -> 32).  fp32 vs the oracle."""
+    from msod_amd.models.configs import named_config
+    from msod_amd.models.yolo_test import Model
+    from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict
+    from oracle.cft_oracle import OracleModel
+    cfg = named_config("yolov5x_fusion_transformer_FLIR")
+    model = Model(cfg)
+    sd = seeded_state_dict(model.state_dict(), 31)
+    model.load_state_dict(sd)
+    rgb, ir = seeded_inputs(1, 128, 160, 31)
+    want_pred, want_raw = OracleModel(cfg)(sd, rgb, ir)
+    pred, raw = _run(model, rgb, ir, dev, torch.float32)
+    for a, c in zip(raw, want_raw):
+        assert a.shape == c.shape and (a - c).abs().max().item() <= 1e-3
+    assert torch.allclose(pred, want_pred, rtol=1e-3, atol=1e-3)
+    pred16, raw16 = _run(model, rgb, ir, dev, torch.bfloat16)
+    a = torch.cat([r.reshape(-1) for r in raw16]); b = torch.cat([r.reshape(-1) for r in want_raw])
+    assert ((a - b).pow(2).mean().sqrt() / b.std()).item() <= BF16_LOGIT_RMS
