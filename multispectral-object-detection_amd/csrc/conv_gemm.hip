@@ -163,8 +163,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc
   }
 }
 
-// ABLATE (tuning only): 0 = normal; 1 = no global loads after the first tile (compute-only bound);
-// 2 = no MFMA (staging-only bound); 3 = neither (barrier / address-math skeleton).
+// ABLATE (tuning only, bit mask): 1 = no global loads after the first tile (compute-only bound); 2 = no MFMA
+// (staging-only bound); 16 = no epilogue (no bias/activation/residual/stores).
 template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvParams p) {
   constexpr int NTHR = 64 * WGM * WGN;
@@ -325,6 +325,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
 #undef CFT_LOAD_TILE
 #undef CFT_STORE_TILE
 
+  if constexpr (ABLATE & 16) {   // timing probe: no epilogue (keep the accumulators alive)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
   conv_epilogue<WM, WN>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
@@ -377,6 +384,8 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
     case 30: return launch_conv<T, 512, 128, 8, 2, true>(p, stream);
     case 32: return launch_conv<T, 512, 64, 8, 2, true>(p, stream);
     case 33: return launch_conv<T, 256, 128, 4, 2, true>(p, stream);
+    case 51: return launch_conv<T, 192, 128, 2, 4, true>(p, stream);
+    case 1627: return launch_conv<T, 256, 256, 4, 4, true, 16>(p, stream);
     case 127: return launch_conv<T, 256, 256, 4, 4, true, 1>(p, stream);
     case 227: return launch_conv<T, 256, 256, 4, 4, true, 2>(p, stream);
     case 327: return launch_conv<T, 256, 256, 4, 4, true, 3>(p, stream);
@@ -395,7 +404,9 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
     return launch_conv<T, 64, 64, 2, 2, true>(p, stream);
   }
   if (p.N <= 128) {
-    if (p.Kpad >= 512 && tiles(512, 128) >= kCUs) return launch_conv<T, 512, 128, 8, 2, true>(p, stream);
+    // 192x128 with 8 waves is the largest 128-wide tile of which TWO workgroups fit a CU (80 KiB LDS each): the
+    // store/residual burst of one workgroup's epilogue overlaps the other's K loop (+5..8 % over 512x128x16w).
+    if (tiles(192, 128) >= 2 * kCUs) return launch_conv<T, 192, 128, 2, 4, true>(p, stream);
     if (tiles(128, 128) >= kCUs) return launch_conv<T, 128, 128, 2, 4, true>(p, stream);
     return launch_conv<T, 64, 128, 2, 2, true>(p, stream);
   }
@@ -403,7 +414,7 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   const long pad256 = (long)((p.N + 255) / 256) * 256, pad128 = (long)((p.N + 127) / 128) * 128;
   const bool wide_ok = pad256 * 100 <= pad128 * 115;
   if (wide_ok && p.Kpad >= 256 && tiles(256, 256) >= kCUs) return launch_conv<T, 256, 256, 4, 4, true>(p, stream);
-  if (p.Kpad >= 512 && tiles(512, 128) >= kCUs) return launch_conv<T, 512, 128, 8, 2, true>(p, stream);
+  if (tiles(192, 128) >= 2 * kCUs) return launch_conv<T, 192, 128, 2, 4, true>(p, stream);
   if (p.Kpad >= 512 && tiles(256, 128) >= kCUs) return launch_conv<T, 256, 128, 4, 2, true>(p, stream);
   if (tiles(128, 128) >= kCUs) return launch_conv<T, 128, 128, 2, 4, true>(p, stream);
   return launch_conv<T, 64, 128, 2, 2, true>(p, stream);
