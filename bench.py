@@ -213,6 +213,12 @@ def main():
                            for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])}, fh, indent=1)
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
         achieved = flops / secs / 1e12
+        split = {}
+        for kind in ("conv", "linear"):     # convolutions vs the nn.Linear GEMMs of the CFT (GPT) blocks
+            fl = sum(v[1] for k, v in fam.items() if k.startswith(kind))
+            tt = sum(v[2] for k, v in fam.items() if k.startswith(kind))
+            if tt > 0:
+                split[kind] = {"tflops": round(fl / tt / 1e12, 1), "frac": round(fl / tt / 1e12 / peak, 4), "ms": round(tt * 1e3, 3)}
         line = {
             "metric": "image-pairs/sec fwd, yolov5l+CFTx3 640x640 bs64, 1/2/4/8 GPU",
             "value": round(value, 2), "unit": "image-pairs/sec", "n_gpus": world, "steps": args.steps,
@@ -228,6 +234,7 @@ def main():
                          "event_bracket_overhead_us": round(ovh * 1e6, 2),
                          "avg_launch_us": round(secs / n_launch * 1e6, 2),
                          "flops_per_step": flops, "gemm_time_share_of_step": round(secs * 1e3 / ms, 3),
+                         "by_block": {"backbone_head_convs": split.get("conv"), "cft_linears": split.get("linear")},
                          "top_shapes": [{"shape": k, "launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
                                          "ms": round(v[2] * 1e3, 3)} for k, v in top]},
         }

@@ -385,6 +385,8 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
     case 32: return launch_conv<T, 512, 64, 8, 2, true>(p, stream);
     case 33: return launch_conv<T, 256, 128, 4, 2, true>(p, stream);
     case 51: return launch_conv<T, 192, 128, 2, 4, true>(p, stream);
+    case 60: return launch_conv<T, 128, 256, 4, 4, true>(p, stream);
+    case 63: return launch_conv<T, 64, 128, 2, 4, true>(p, stream);
     case 1627: return launch_conv<T, 256, 256, 4, 4, true, 16>(p, stream);
     case 127: return launch_conv<T, 256, 256, 4, 4, true, 1>(p, stream);
     case 227: return launch_conv<T, 256, 256, 4, 4, true, 2>(p, stream);
@@ -407,17 +409,17 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
     // 192x128 with 8 waves is the largest 128-wide tile of which TWO workgroups fit a CU (80 KiB LDS each): the
     // store/residual burst of one workgroup's epilogue overlaps the other's K loop (+5..8 % over 512x128x16w).
     if (tiles(192, 128) >= 2 * kCUs) return launch_conv<T, 192, 128, 2, 4, true>(p, stream);
-    if (tiles(128, 128) >= kCUs) return launch_conv<T, 128, 128, 2, 4, true>(p, stream);
-    return launch_conv<T, 64, 128, 2, 2, true>(p, stream);
+    if (tiles(128, 128) >= 2 * kCUs) return launch_conv<T, 128, 128, 2, 4, true>(p, stream);
+    return launch_conv<T, 64, 128, 2, 4, true>(p, stream);          // few tiles: 3 workgroups of 8 waves per CU
   }
   // wide layers: prefer 256-wide tiles unless the N tail would waste much more than 128-wide tiles do
   const long pad256 = (long)((p.N + 255) / 256) * 256, pad128 = (long)((p.N + 127) / 128) * 128;
   const bool wide_ok = pad256 * 100 <= pad128 * 115;
   if (wide_ok && p.Kpad >= 256 && tiles(256, 256) >= kCUs) return launch_conv<T, 256, 256, 4, 4, true>(p, stream);
+  if (wide_ok && tiles(128, 256) >= kCUs) return launch_conv<T, 128, 256, 4, 4, true>(p, stream);   // e.g. CFT fc2 at M = 8192
   if (tiles(192, 128) >= 2 * kCUs) return launch_conv<T, 192, 128, 2, 4, true>(p, stream);
-  if (p.Kpad >= 512 && tiles(256, 128) >= kCUs) return launch_conv<T, 256, 128, 4, 2, true>(p, stream);
-  if (tiles(128, 128) >= kCUs) return launch_conv<T, 128, 128, 2, 4, true>(p, stream);
-  return launch_conv<T, 64, 128, 2, 2, true>(p, stream);
+  if (tiles(128, 128) >= 2 * kCUs) return launch_conv<T, 128, 128, 2, 4, true>(p, stream);
+  return launch_conv<T, 64, 128, 2, 4, true>(p, stream);
 }
 
 extern "C" int cft_conv2d(const void* x, const void* w, const float* bias, const void* res, void* y,

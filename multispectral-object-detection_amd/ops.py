@@ -126,14 +126,14 @@ def set_launch_log(log):
     _launch_log = log
 
 
-def _timed_gemm(lib, rows, pk, args, abytes=0.0):
+def _timed_gemm(lib, rows, pk, args, abytes=0.0, kind="conv"):
     if _launch_log is None:
         return lib.cft_conv2d(*args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     st = lib.cft_conv2d(*args)
     e1.record()
-    _launch_log.append((f"k{pk.k}s{pk.s}_n{pk.n}_K{pk.kpad}", rows * pk.flops_per_row, e0, e1, abytes))
+    _launch_log.append((f"{kind}_k{pk.k}s{pk.s}_n{pk.n}_K{pk.kpad}", rows * pk.flops_per_row, e0, e1, abytes))
     return st
 
 
@@ -187,7 +187,7 @@ def linear(x, pk, act=ACT_NONE, residual=None, out=None, out_dtype=None):
     st = _timed_gemm(lib, rows, pk,
                      (x.data_ptr(), pk.w.data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None, rp,
                       out.data_ptr(), 1, 1, rows, pk.cin, x.stride(0), 0, pk.n, pk.kpad, 1, 1,
-                      out.stride(0), 0, ldr, 0, act, _dt(x.dtype), _dt(out.dtype), rdt, _stream()), abytes)
+                      out.stride(0), 0, ldr, 0, act, _dt(x.dtype), _dt(out.dtype), rdt, _stream()), abytes, kind="linear")
     _lib.check(st, "cft_conv2d(linear)")
     return out
 

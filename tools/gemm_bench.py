@@ -39,6 +39,13 @@ SHAPES = [
     ("GPT fc2 4096->1024", 1, 1, 8192, 4096, 1024, 1, 1, False, 8),
     ("GPT out 512->512", 1, 1, 8192, 512, 512, 1, 1, False, 8),
     ("GPT fc1 256->1024", 1, 1, 8192, 256, 1024, 1, 1, False, 8),
+    ("GPT out 1024->1024", 1, 1, 8192, 1024, 1024, 1, 1, False, 8),
+    ("GPT qkv 512->1536", 1, 1, 8192, 512, 1536, 1, 1, False, 8),
+    ("GPT fc1 512->2048", 1, 1, 8192, 512, 2048, 1, 1, False, 8),
+    ("GPT fc2 2048->512", 1, 1, 8192, 2048, 512, 1, 1, False, 8),
+    ("GPT qkv 256->768", 1, 1, 8192, 256, 768, 1, 1, False, 8),
+    ("GPT out 256->256", 1, 1, 8192, 256, 256, 1, 1, False, 8),
+    ("GPT fc2 1024->256", 1, 1, 8192, 1024, 256, 1, 1, False, 8),
 ]
 
 
