@@ -380,34 +380,40 @@ extern "C" int cft_layernorm(const float* x, const float* gamma, const float* be
 // ------------------------------------------------------------------------------- CFT de-tokeniser
 // out = base + bilinear(tokens 8x8 -> HxW), PyTorch align_corners=False source index:
 // src = (dst + 0.5) * (8 / size) - 0.5, clamped at 0; neighbour clamped at 7.
+// One workgroup per output image row (b, y): the two token rows that the bilinear filter touches are blended
+// in y ONCE into LDS (8 cells x C floats), then every output granule needs two LDS reads instead of four
+// 32-byte token fetches from L2 (the token traffic was 8x the output traffic).
 template <typename T>
 __global__ void __launch_bounds__(256) gpt_upsample_add_kernel(const float* __restrict__ tokens, int s,
                                                                const unsigned char* base, long ldb_b, long boff_b,
                                                                unsigned char* out, long ldo_b, long ooff_b,
                                                                int B, int H, int W, int C) {
   constexpr int GE = Elem<T>::GE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* R = reinterpret_cast<float*>(smem);          // [8][C]
+  const int b = blockIdx.x / H, y = blockIdx.x - b * H;
+  float fy = ((float)y + 0.5f) * (8.0f / (float)H) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+  const int y0 = (int)fy, y1 = y0 + (y0 < 7 ? 1 : 0);
+  const float ly = fy - (float)y0, hy = 1.f - ly;
+  const float* t0 = tokens + ((long)b * 128 + s * 64 + y0 * 8) * C;
+  const float* t1 = tokens + ((long)b * 128 + s * 64 + y1 * 8) * C;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {          // 8*C/4 float4
+    const float4 a = reinterpret_cast<const float4*>(t0)[i], c = reinterpret_cast<const float4*>(t1)[i];
+    reinterpret_cast<float4*>(R)[i] = make_float4(hy * a.x + ly * c.x, hy * a.y + ly * c.y, hy * a.z + ly * c.z, hy * a.w + ly * c.w);
+  }
+  __syncthreads();
   const int gpp = C / GE;
-  const long total = (long)B * H * W * gpp;
-  const float sy = 8.0f / (float)H, sx = 8.0f / (float)W;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int cg = (int)(idx % gpp);
-    long t = idx / gpp;
-    const int x = (int)(t % W); t /= W;
-    const int y = (int)(t % H);
-    const int b = (int)(t / H);
-    float fy = ((float)y + 0.5f) * sy - 0.5f; fy = fy < 0.f ? 0.f : fy;
+  const float sx = 8.0f / (float)W;
+  const long rowpix = ((long)b * H + y) * W;
+  for (int idx = threadIdx.x; idx < W * gpp; idx += blockDim.x) {
+    const int x = idx / gpp, cg = idx - x * gpp;
     float fx = ((float)x + 0.5f) * sx - 0.5f; fx = fx < 0.f ? 0.f : fx;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < 7 ? 1 : 0), x1 = x0 + (x0 < 7 ? 1 : 0);
-    const float ly = fy - (float)y0, lx = fx - (float)x0;
-    const float hy = 1.f - ly, hx = 1.f - lx;
-    const float* tb = tokens + ((long)b * 128 + s * 64) * C + cg * GE;
-    const float* p00 = tb + (long)(y0 * 8 + x0) * C;
-    const float* p01 = tb + (long)(y0 * 8 + x1) * C;
-    const float* p10 = tb + (long)(y1 * 8 + x0) * C;
-    const float* p11 = tb + (long)(y1 * 8 + x1) * C;
+    const int x0 = (int)fx, x1 = x0 + (x0 < 7 ? 1 : 0);
+    const float lx = fx - (float)x0, hx = 1.f - lx;
+    const float* r0 = R + x0 * C + cg * GE;
+    const float* r1 = R + x1 * C + cg * GE;
     float v[GE];
-    const long pix = ((long)b * H + y) * W + x;
+    const long pix = rowpix + x;
     if (base != nullptr) {
       Elem<T>::unpack(*reinterpret_cast<const gran_t*>(base + pix * ldb_b + boff_b + cg * 16L), v);
     } else {
@@ -415,7 +421,7 @@ __global__ void __launch_bounds__(256) gpt_upsample_add_kernel(const float* __re
       for (int e = 0; e < GE; ++e) v[e] = 0.f;
     }
 #pragma unroll
-    for (int e = 0; e < GE; ++e) v[e] += hy * (hx * p00[e] + lx * p01[e]) + ly * (hx * p10[e] + lx * p11[e]);
+    for (int e = 0; e < GE; ++e) v[e] += hx * r0[e] + lx * r1[e];
     *reinterpret_cast<gran_t*>(out + pix * ldo_b + ooff_b + cg * 16L) = Elem<T>::pack(v);
   }
 }
@@ -428,13 +434,15 @@ extern "C" int cft_gpt_upsample_add(const float* tokens, int s, const void* base
   CFT_REQUIRE(s == 0 || s == 1, "cft_gpt_upsample_add: stream index must be 0 or 1");
   const int ge = dtype == CFT_BF16 ? 8 : 4, es = dtype == CFT_BF16 ? 2 : 4;
   CFT_REQUIRE(C % ge == 0 && ldo % ge == 0 && ooff % ge == 0 && (base == nullptr || (ldb % ge == 0 && boff % ge == 0)), "cft_gpt_upsample_add: not granule aligned");
-  const long total = (long)B * H * W * (C / ge);
-  const int grid = grid_for(total, 256);
+  CFT_REQUIRE(C % 4 == 0 && (long)B * H < (1L << 31), "cft_gpt_upsample_add: C must be a multiple of 4");
+  const int grid = B * H;
+  const size_t smem = (size_t)8 * C * sizeof(float);
+  CFT_REQUIRE(smem <= 64 * 1024, "cft_gpt_upsample_add: C too large for the LDS row (C <= 2048)");
   if (dtype == CFT_BF16)
-    hipLaunchKernelGGL(gpt_upsample_add_kernel<uint16_t>, dim3(grid), dim3(256), 0, as_stream(stream), tokens, s, (const unsigned char*)base, (long)ldb * es, (long)boff * es,
+    hipLaunchKernelGGL(gpt_upsample_add_kernel<uint16_t>, dim3(grid), dim3(256), smem, as_stream(stream), tokens, s, (const unsigned char*)base, (long)ldb * es, (long)boff * es,
                        (unsigned char*)out, (long)ldo * es, (long)ooff * es, B, H, W, C);
   else
-    hipLaunchKernelGGL(gpt_upsample_add_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), tokens, s, (const unsigned char*)base, (long)ldb * es, (long)boff * es,
+    hipLaunchKernelGGL(gpt_upsample_add_kernel<float>, dim3(grid), dim3(256), smem, as_stream(stream), tokens, s, (const unsigned char*)base, (long)ldb * es, (long)boff * es,
                        (unsigned char*)out, (long)ldo * es, (long)ooff * es, B, H, W, C);
   return cft_check_launch("gpt_upsample_add_kernel");
 }
