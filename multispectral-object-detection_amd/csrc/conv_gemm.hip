@@ -80,6 +80,30 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4_t 
     const int n = n0 + wn * WN + j * 16 + lrow;
     bias_v[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.0f;
   }
+  // bf16 residual (Bottleneck shortcut): every strip's residual vectors are requested up front, so their HBM
+  // latency runs under the activation / LDS work instead of once per strip.  (The lane that reads an element is
+  // the lane that later stores it, so an in-place residual stays correct.)
+  constexpr int VPRB = WN / 8;                       // 16-B bf16 vectors per strip row
+  constexpr int VPL = (16 * VPRB + 63) / 64;         // vectors per lane per strip
+  constexpr int RDEPTH = (MT * VPL <= 6) ? MT : 2;   // strips of residual in flight (register budget: 16-wave tiles keep 2)
+  gran_t rpre[OUT_F32 ? 1 : RDEPTH][OUT_F32 ? 1 : VPL];
+  const bool res_pre = !OUT_F32 && p.res != nullptr && !p.res_f32;   // uniform
+#define CFT_RES_FETCH(strip_)                                                                          \
+  _Pragma("unroll") for (int v_ = 0; v_ < VPL; ++v_) {                                                 \
+    const int it_ = lane + v_ * 64;                                                                    \
+    const int row_ = it_ / VPRB, col_ = (it_ - row_ * VPRB) * 8;                                       \
+    const int m_ = m0 + wm * WM + (strip_) * 16 + row_, n_ = n0 + wn * WN + col_;                      \
+    gran_t t_ = {0u, 0u, 0u, 0u};                                                                      \
+    if (it_ < 16 * VPRB && m_ < p.M && n_ < p.N)                                                       \
+      t_ = *reinterpret_cast<const gran_t*>(p.res + ((long)m_ * p.ldr + p.roff + n_) * 2);             \
+    rpre[(strip_) % RDEPTH][v_] = t_;                                                                  \
+  }
+  if constexpr (!OUT_F32) {
+    if (res_pre) {
+#pragma unroll
+      for (int i = 0; i < RDEPTH; ++i) CFT_RES_FETCH(i)
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -116,37 +140,39 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4_t 
       }
     } else {
       constexpr int VPR = WN / 8;
-      for (int it = lane; it < 16 * VPR; it += 64) {
+#pragma unroll
+      for (int vi = 0; vi < VPL; ++vi) {
+        const int it = lane + vi * 64;
         const int row = it / VPR, col = (it - row * VPR) * 8;
         const int m = mbase + row, n = nbase + col;
-        if (m < p.M && n < p.N) {
+        if (it < 16 * VPR && m < p.M && n < p.N) {
           const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col);
           const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col + 4);
           float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-          if (p.res != nullptr) {
-            const long ro = (long)m * p.ldr + p.roff + n;
-            if (p.res_f32) {
-              const float4 r0v = *reinterpret_cast<const float4*>(p.res + ro * 4);
-              const float4 r1v = *reinterpret_cast<const float4*>(p.res + ro * 4 + 16);
-              v[0] += r0v.x; v[1] += r0v.y; v[2] += r0v.z; v[3] += r0v.w;
-              v[4] += r1v.x; v[5] += r1v.y; v[6] += r1v.z; v[7] += r1v.w;
-            } else {
-              const gran_t rr = *reinterpret_cast<const gran_t*>(p.res + ro * 2);
-              float rf[8];
-              Elem<uint16_t>::unpack(rr, rf);
+          if (res_pre) {
+            float rf[8];
+            Elem<uint16_t>::unpack(rpre[i % RDEPTH][vi], rf);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += rf[e];
-            }
+            for (int e = 0; e < 8; ++e) v[e] += rf[e];
+          } else if (p.res != nullptr) {   // fp32 residual stream of the CFT block
+            const long ro = (long)m * p.ldr + p.roff + n;
+            const float4 r0v = *reinterpret_cast<const float4*>(p.res + ro * 4);
+            const float4 r1v = *reinterpret_cast<const float4*>(p.res + ro * 4 + 16);
+            v[0] += r0v.x; v[1] += r0v.y; v[2] += r0v.z; v[3] += r0v.w;
+            v[4] += r1v.x; v[5] += r1v.y; v[6] += r1v.z; v[7] += r1v.w;
           }
           *reinterpret_cast<gran_t*>(p.y + ((long)m * p.ldy + p.yoff + n) * 2) = Elem<uint16_t>::pack(v);
         }
       }
+      if (res_pre && i + RDEPTH < MT) CFT_RES_FETCH(i + RDEPTH)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
+
+#undef CFT_RES_FETCH
 
 // Uniform dispatch to the specialised epilogues (one activation / output type per launch).
 template <int WM, int WN>
