@@ -62,7 +62,7 @@ def main():
     results = []
     g = torch.Generator().manual_seed(0)
     for name, B, H, W, Cin, N, k, s, use_res, count in SHAPES:
-        if args.only and args.only not in name:
+        if args.only and not any(o in name for o in args.only.split('|')):
             continue
         x = ops.new_nhwc(B, H, W, Cin, dtype, dev)
         x.copy_(torch.randn(x.shape, device=dev) )
