@@ -83,6 +83,18 @@ int cft_focus_s2d_u8(const unsigned char* in, long stride_b, long stride_c, long
                      int B, int H, int W, float scale, int dtype, void* stream);
 
 /*
+ * Focus in one kernel: the space-to-depth above plus its 3x3 Conv (+ folded BN, + SiLU; models/common.py:168-179
+ * with :45-50) straight from the image, bf16 compute, no intermediate tensor.  `in` is the first channel of the
+ * stream: float (in_u8 = 0, scale = 1) or unsigned char (in_u8 = 1, scale = 1/255; test.py:106-113), element
+ * strides for batch / channel / row, row elements contiguous, pointer and strides multiples of 2 elements.
+ * w: bf16 [n][192], k = (kh*3 + kw)*16 + ci, ci < 12 real (the cft_conv2d layout for cin = 16); n in {32,48,64,80};
+ * y: bf16 NHWC [B,H/2,W/2] with ldy/yoff.  Bit-identical to cft_focus_s2d(_u8) followed by cft_conv2d.
+ */
+int cft_focus_conv(const void* in, int in_u8, long stride_b, long stride_c, long stride_h, float scale,
+                   const void* w, int kpad, const float* bias, void* y, int ldy, int yoff,
+                   int B, int H, int W, int n, int act, void* stream);
+
+/*
  * SPP max pools (models/common.py:161-165): reads channels [0,C) of the NHWC buffer `buf`
  * (ld channels/pixel) and writes max_pool2d(k, stride 1, pad k/2) for k = k1,k2,k3 to channel
  * slices [C,2C), [2C,3C), [3C,4C) of the same buffer.  k odd, <= 13, k1 <= k2 <= k3.

@@ -71,6 +71,14 @@ __device__ __forceinline__ f32x4_t mma_granule<float>(const gran_t& a, const gra
   return c;
 }
 
+// Fused epilogue activations (one instantiation per activation, selected uniformly per launch).
+template <int ACT>
+__device__ __forceinline__ float apply_act(float v) {
+  if constexpr (ACT == CFT_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));   // x*sigmoid(x): v_exp + v_rcp
+  if constexpr (ACT == CFT_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+  return v;
+}
+
 // ---- host side -----------------------------------------------------------------------------
 void cft_set_error(const char* msg);
 int cft_check_launch(const char* what);

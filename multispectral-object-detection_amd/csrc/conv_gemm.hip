@@ -53,13 +53,6 @@ __device__ __forceinline__ int fast_div(int n, uint32_t mul, uint32_t sh) {
 
 __device__ __attribute__((aligned(16))) uint32_t cft_zero_page[4] = {0u, 0u, 0u, 0u};
 
-template <int ACT>
-__device__ __forceinline__ float apply_act(float v) {
-  if constexpr (ACT == CFT_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));   // x*sigmoid(x): v_exp + v_rcp
-  if constexpr (ACT == CFT_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-  return v;
-}
-
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 

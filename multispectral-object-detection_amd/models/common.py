@@ -240,8 +240,7 @@ class Focus(_Packed):
 
     def forward(self, x):
         x = resolve(x)
-        z = ops.focus_s2d(x, self.compute_dtype)
-        return ops.conv2d(z, self._packed(z.dtype, z.device), _act_code(self.conv.act))
+        return ops.focus_conv(x, self._packed(self.compute_dtype, x.device), _act_code(self.conv.act), self.compute_dtype)
 
 
 class Upsample(nn.Upsample):

@@ -217,6 +217,45 @@ def focus_s2d(img, dtype):
     return out
 
 
+def focus_conv(img, pk, act, dtype):
+    """Focus = space-to-depth + 3x3 Conv of the image batch ``img`` ([B,3,H,W] float or uint8, NCHW).
+    bf16 with 32/48/64/80 output channels runs as ONE kernel (cft_focus_conv: no intermediate tensor, bit-identical);
+    anything else as cft_focus_s2d + cft_conv2d."""
+    _require_cuda(img, "focus_conv")
+    if img.dim() != 4 or img.shape[1] != 3:
+        raise ValueError(f"focus_conv: expected a [B,3,H,W] image batch, got {tuple(img.shape)}")
+    fusable = (dtype == torch.bfloat16 and pk.k == 3 and pk.s == 1 and pk.cin == 16 and pk.kpad == 192
+               and pk.n in (32, 48, 64, 80) and act in (ACT_NONE, ACT_SILU))
+    if not fusable:
+        return conv2d(focus_s2d(img, dtype), pk, act)
+    if img.dtype != torch.uint8 and img.dtype != torch.float32:
+        img = img.float()
+    es = img.element_size()
+    if img.stride(3) != 1 or any(img.stride(i) % 2 for i in range(3)) or img.data_ptr() % (2 * es):
+        img = img.contiguous()
+    B, _, H, W = img.shape
+    if H % 2 or W % 2:
+        raise ValueError("focus_conv: H and W must be even")
+    u8 = img.dtype == torch.uint8
+    out = new_nhwc(B, H // 2, W // 2, pk.n, dtype, img.device)
+    lib = _lib.load()
+    args = (img.data_ptr(), 1 if u8 else 0, img.stride(0), img.stride(1), img.stride(2), 1.0 / 255.0 if u8 else 1.0,
+            pk.w.data_ptr(), pk.kpad, pk.bias.data_ptr() if pk.bias is not None else None, out.data_ptr(),
+            _view_ld(out, "focus_conv out"), 0, B, H, W, pk.n, act, _stream())
+    if _launch_log is None:
+        st = lib.cft_focus_conv(*args)
+    else:   # counted with the GEMM family (it is the same implicit-GEMM MFMA work, on a dedicated kernel)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        st = lib.cft_focus_conv(*args)
+        e1.record()
+        rows = B * (H // 2) * (W // 2)
+        abytes = img.numel() * es + rows * pk.n_valid * 2 + pk.w.numel() * 2
+        _launch_log.append((f"conv_focus_k3s1_n{pk.n}_K{pk.kpad}", rows * pk.flops_per_row, e0, e1, abytes))
+    _lib.check(st, "cft_focus_conv")
+    return out
+
+
 def spp_maxpool(buf, C, ks):
     """In-place: buf [B,4C,H,W] NHWC, channels [0,C) already hold x; fills the three pooled slices."""
     _require_cuda(buf, "spp_maxpool")

@@ -300,3 +300,34 @@ def test_focus_uint8_pair(dev, dtype):
         zf = ops.focus_s2d(ref[:, lo:lo + 3].contiguous().to(dev), dtype)
         torch.cuda.synchronize()
         assert rel_err(to_cpu_f32(z8), to_cpu_f32(zf)) < (1e-6 if dtype == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("n", [32, 48, 64, 80])
+@pytest.mark.parametrize("hw", [(32, 32), (96, 160), (40, 296)])
+def test_focus_conv_fused_is_bit_identical(dev, n, hw):
+    """cft_focus_conv (image -> space-to-depth -> 3x3 conv -> SiLU in one kernel) against the two-kernel path
+    (cft_focus_s2d + cft_conv2d), for float and uint8 images: same products, same k order -> same bits; and
+    against the oracle's Focus within the bf16 tolerance."""
+    from msod_amd import ops
+    from oracle import cft_oracle as O
+    H, W = hw
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(50 + n)
+    sd = {"f.conv.conv.weight": _q(_rnd(n, 12, 3, 3, seed=51, scale=0.1), dtype), "f.conv.conv.bias": _rnd(n, seed=52, scale=0.1)}
+    pk = ops.pack_conv(sd["f.conv.conv.weight"], sd["f.conv.conv.bias"], dtype, cin_pad=16, device=dev)
+    img = torch.rand(3, 3, H, W, generator=g)
+    img6 = torch.randint(0, 256, (3, 6, H, W), dtype=torch.uint8, generator=g).to(dev)
+    for act in (1, 0):
+        fused = ops.focus_conv(img.to(dev), pk, act, dtype)
+        two = ops.conv2d(ops.focus_s2d(img.to(dev), dtype), pk, act)
+        torch.cuda.synchronize()
+        assert torch.equal(fused.float().cpu(), two.float().cpu()), f"float image, act={act}"
+    for lo in (0, 3):
+        view = img6[:, lo:lo + 3]
+        fused = ops.focus_conv(view, pk, 1, dtype)
+        two = ops.conv2d(ops.focus_s2d(view, dtype), pk, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(fused.float().cpu(), two.float().cpu()), f"uint8 view at channel {lo}"
+    y = ops.focus_conv(img.to(dev), pk, 1, dtype)
+    torch.cuda.synchronize()
+    assert rel_err(to_cpu_f32(y), O.focus(sd, "f.", _q(img, dtype), 3, 1)) < tol(dtype)
