@@ -61,6 +61,17 @@ int cft_conv2d(const void* x, const void* w, const float* bias, const void* res,
                int ldy, int yoff, int ldr, int roff,
                int act, int dtype, int out_dtype, int res_dtype, void* stream);
 
+/*
+ * Bottleneck as one kernel (models/common.py:99-109 with e = 1.0, the form C3 uses :138):
+ *   y = (shortcut ? x : 0) + SiLU(conv3x3(SiLU(conv1x1(x) + b1)) + b2),  c -> c -> c channels, c = 64, bf16.
+ * x, y: NHWC channel slices (ldx/xoff, ldy/yoff) that must not overlap (the kernel reads a halo of x);
+ * w1 [c][kpad1] and w2 [c][kpad2] in the cft_conv2d layout (BN folded).  Bit-identical to two cft_conv2d calls
+ * (1x1 + SiLU, then 3x3 + SiLU + residual); the hidden tensor never reaches HBM.
+ */
+int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, int kpad1, const float* b1,
+                   const void* w2, int kpad2, const float* b2, void* y, int ldy, int yoff,
+                   int B, int H, int W, int c, int shortcut, void* stream);
+
 /* Tuning knob: force one tile configuration of cft_conv2d (0 = automatic, the default; see
  * csrc/conv_gemm.hip for the table).  Returns the previous value.  Not needed for normal use. */
 int cft_set_conv_variant(int variant);

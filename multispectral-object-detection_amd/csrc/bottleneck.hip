@@ -1,0 +1,241 @@
+// Bottleneck as ONE kernel for the 64-channel stage (gfx950):  y = x + SiLU(conv3x3(SiLU(conv1x1(x))))
+// (reference models/common.py:99-109 with e = 1.0 as used inside C3, Conv = conv + folded BN + SiLU :45-50).
+//
+// As two cft_conv2d launches this stage is the least efficient part of the forward (160x160 maps, 64 channels:
+// K = 64 / 576 is too short to amortise a GEMM workgroup's prologue and epilogue, and the hidden tensor `t` makes a
+// round trip through HBM).  Here a workgroup of 8 waves owns a band of 8 output rows and walks along it in tiles of
+// 32 pixels; the 3x3 weights (9 x 64 x 64 bf16 = 72 KiB) stay in LDS for the whole band:
+//   phase 1  t = SiLU(W1 x + b1) on the 10 x 34 pixel halo patch (zero outside the image = the 3x3 conv's padding):
+//            A fragments straight from global memory (a pixel's 64 channels are one 128-B run), W1 fragments live in
+//            registers, result rounded to bf16 into LDS (128-B rows, granule slot ^ (row & 7));
+//   phase 2  one output row per wave: 32 pixels x 64 channels, 9 taps x 2 MFMAs per 16x16 tile, A fragments are
+//            shifted ds_read_b128 of the t patch, B fragments ds_read_b128 of the resident weights;
+//   epilogue bias + SiLU -> fp32 strip -> 16-B row vectors -> + shortcut -> bf16 -> store (as in conv_gemm.hip).
+// The image loads of tile i+1 (phase-1 operands) and the shortcut vectors are requested before phase 2 of tile i.
+// Products, 32-wide k chunks, their order and every rounding are those of the two-launch path: bit-identical.
+#include "cft_common.h"
+
+struct BneckParams {
+  const unsigned char* x;    // bf16 NHWC, ldx channels per pixel, slice offset xoff
+  const unsigned char* w1;   // bf16 [C][kpad1]
+  const unsigned char* w2;   // bf16 [C][kpad2], k = (kh*3 + kw)*C + ci
+  const float* b1;
+  const float* b2;
+  unsigned char* y;          // bf16 NHWC, ldy / yoff; must not overlap x (halo reads)
+  int ldx, xoff, ldy, yoff, kpad1, kpad2;
+  int H, W, tiles_x, bands, shortcut;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(512) bottleneck_kernel(const BneckParams p) {
+  static_assert(NT == 4, "the LDS layout below is for 64 channels (128-byte pixel rows)");
+  constexpr int C = NT * 16, TW = 32, TH = 8, PW = TW + 2, PH = TH + 2;
+  constexpr int NPIX = PH * PW;                 // 340 patch pixels
+  constexpr int NRT = (NPIX + 15) / 16;         // 22 MFMA row tiles of the patch
+  constexpr int RTW = (NRT + 7) / 8;            // row tiles per wave (3)
+  constexpr int W2_BYTES = 9 * C * 128;
+  constexpr int SLD = C + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sW2 = smem;
+  unsigned char* sT = smem + W2_BYTES;          // t patch [NRT*16][128 B]; re-used for the epilogue strips
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  const int b = blockIdx.x / p.bands, band = blockIdx.x - b * p.bands;
+  const int y0 = band * TH;
+  const long img_pix = (long)b * p.H * p.W;
+
+  // 3x3 weights -> LDS, per tap a [C][128 B] tile, slot = k-granule ^ (row & 7)
+  for (int idx = tid; idx < 9 * C * 8; idx += 512) {
+    const int tap = idx / (C * 8);
+    const int r = idx - tap * (C * 8);
+    const int n = r >> 3, s = r & 7, g = s ^ (n & 7);
+    *reinterpret_cast<gran_t*>(sW2 + tap * (C * 128) + n * 128 + (s << 4)) =
+        *reinterpret_cast<const gran_t*>(p.w2 + ((long)n * p.kpad2 + tap * C + g * 8) * 2);
+  }
+  // 1x1 weights: B fragments in registers (lane: row n = j*16 + lrow, k = ks*32 + lgrp*8 ..)
+  gran_t w1f[NT][2];
+  float b1v[NT], b2v[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = j * 16 + lrow;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      w1f[j][ks] = *reinterpret_cast<const gran_t*>(p.w1 + ((long)n * p.kpad1 + ks * 32 + lgrp * 8) * 2);
+    b1v[j] = p.b1 != nullptr ? p.b1[n] : 0.0f;
+    b2v[j] = p.b2 != nullptr ? p.b2[n] : 0.0f;
+  }
+  float* stage = reinterpret_cast<float*>(sT) + wave * (16 * SLD);
+  const int y = y0 + wave;   // this wave's output row
+
+  gran_t a1[RTW][2];
+// phase-1 operands of tile tx_: patch pixel q = rt*16 + lrow of row tile rt = wave + 8*it (zero outside the image)
+#define BNECK_FETCH(tx_)                                                                                \
+  _Pragma("unroll") for (int it = 0; it < RTW; ++it) {                                                  \
+    const int q = (wave + it * 8) * 16 + lrow;                                                          \
+    const int py = q / PW, px = q - py * PW;                                                            \
+    const int zy = y0 - 1 + py, zx = (tx_) * TW - 1 + px;                                               \
+    gran_t t0 = {0u, 0u, 0u, 0u}, t1 = {0u, 0u, 0u, 0u};                                                \
+    if (q < NPIX && (unsigned)zy < (unsigned)p.H && (unsigned)zx < (unsigned)p.W) {                     \
+      const unsigned char* src = p.x + ((img_pix + (long)zy * p.W + zx) * p.ldx + p.xoff + lgrp * 8) * 2; \
+      t0 = *reinterpret_cast<const gran_t*>(src);                                                       \
+      t1 = *reinterpret_cast<const gran_t*>(src + 64);                                                  \
+    }                                                                                                   \
+    a1[it][0] = t0;                                                                                     \
+    a1[it][1] = t1;                                                                                     \
+  }
+  BNECK_FETCH(0)
+
+  for (int tx = 0; tx < p.tiles_x; ++tx) {
+    const int x0 = tx * TW;
+    // ---- phase 1: t patch -> LDS
+#pragma unroll
+    for (int it = 0; it < RTW; ++it) {
+      const int rt = wave + it * 8;
+      if (rt < NRT) {   // wave-uniform
+        f32x4_t acc1[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc1[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) acc1[j] = mma_granule<uint16_t>(a1[it][ks], w1f[j][ks], acc1[j]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = rt * 16 + lgrp * 4 + e;
+          const int py = q / PW, px = q - py * PW;
+          const int zy = y0 - 1 + py, zx = x0 - 1 + px;
+          const bool inside = q < NPIX && (unsigned)zy < (unsigned)p.H && (unsigned)zx < (unsigned)p.W;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int n = j * 16 + lrow;
+            const float v = inside ? apply_act<CFT_ACT_SILU>(acc1[j][e] + b1v[j]) : 0.0f;
+            *reinterpret_cast<uint16_t*>(sT + q * 128 + ((((n >> 3) ^ (q & 7)) << 4) | ((n & 7) << 1))) =
+                (uint16_t)(pack_bf16x2(v, 0.0f) & 0xffffu);
+          }
+        }
+      }
+    }
+    __syncthreads();   // t patch (and, the first time, the 3x3 weights) complete
+
+    // requests that land under phase 2: next tile's phase-1 operands, this tile's shortcut vectors
+    if (tx + 1 < p.tiles_x) BNECK_FETCH(tx + 1)
+    gran_t rs[2][2];
+    if (p.shortcut) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const int it = lane + v * 64;
+          const int row = it >> 3, col = (it & 7) * 8;
+          const int x = x0 + i * 16 + row;
+          gran_t t = {0u, 0u, 0u, 0u};
+          if (x < p.W && y < p.H)
+            t = *reinterpret_cast<const gran_t*>(p.x + ((img_pix + (long)y * p.W + x) * p.ldx + p.xoff + col) * 2);
+          rs[i][v] = t;
+        }
+    }
+
+    // ---- phase 2: 3x3 conv of the t patch, one output row (32 pixels) per wave
+    f32x4_t acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {   // not unrolled: the compiler otherwise hoists all 72 weight fragments (spills)
+      const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kg = ks * 4 + lgrp;
+        gran_t af[2], bf[NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int q = (wave + kh) * PW + i * 16 + lrow + kw;
+          af[i] = *reinterpret_cast<const gran_t*>(sT + q * 128 + ((kg ^ (q & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = j * 16 + lrow;
+          bf[j] = *reinterpret_cast<const gran_t*>(sW2 + tap * (C * 128) + n * 128 + ((kg ^ (n & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mma_granule<uint16_t>(af[i], bf[j], acc[i][j]);
+      }
+    }
+    __syncthreads();   // every wave is done with the t patch before the strips overwrite it
+
+    // ---- epilogue: bias + SiLU -> strip -> (+ shortcut) -> bf16 rows
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          stage[(lgrp * 4 + e) * SLD + j * 16 + lrow] = apply_act<CFT_ACT_SILU>(acc[i][j][e] + b2v[j]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int it = lane + v * 64;
+        const int row = it >> 3, col = (it & 7) * 8;
+        const int x = x0 + i * 16 + row;
+        if (x < p.W && y < p.H) {
+          const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col);
+          const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col + 4);
+          float o[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+          if (p.shortcut) {
+            float rf[8];
+            Elem<uint16_t>::unpack(rs[i][v], rf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += rf[e];
+          }
+          *reinterpret_cast<gran_t*>(p.y + ((img_pix + (long)y * p.W + x) * p.ldy + p.yoff + col) * 2) = Elem<uint16_t>::pack(o);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();   // strips are dead before the next t patch is written
+  }
+#undef BNECK_FETCH
+}
+
+extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, int kpad1, const float* b1,
+                              const void* w2, int kpad2, const float* b2, void* y, int ldy, int yoff,
+                              int B, int H, int W, int c, int shortcut, void* stream) {
+  CFT_REQUIRE(x && w1 && w2 && y, "cft_bottleneck: null pointer");
+  CFT_REQUIRE(c == 64, "cft_bottleneck: the fused kernel covers 64 channels (use two cft_conv2d calls otherwise)");
+  CFT_REQUIRE(B > 0 && H > 0 && W > 0, "cft_bottleneck: non-positive size");
+  CFT_REQUIRE(kpad1 >= c && kpad1 % 64 == 0 && kpad2 >= 9 * c && kpad2 % 64 == 0, "cft_bottleneck: weights must be packed as for cft_conv2d");
+  CFT_REQUIRE(ldx % 8 == 0 && xoff % 8 == 0 && ldy % 8 == 0 && yoff % 8 == 0 && ldx >= xoff + c && ldy >= yoff + c,
+              "cft_bottleneck: ld/offset must be multiples of 8 and cover the channel slice");
+  CFT_REQUIRE((long)B * H * W * ldx < (1L << 31) && (long)B * H * W * ldy < (1L << 31), "cft_bottleneck: tensor exceeds 2^31 elements");
+  {   // the kernel reads a halo of x: the output may share a buffer with x only as a disjoint channel slice
+    const char* xa = (const char*)x + (long)xoff * 2;
+    const char* ya = (const char*)y + (long)yoff * 2;
+    const long xbytes = (long)B * H * W * ldx * 2, ybytes = (long)B * H * W * ldy * 2;
+    const long d = ya > xa ? ya - xa : xa - ya;
+    const bool disjoint_mem = ya + ybytes <= xa || xa + xbytes <= ya;
+    const bool disjoint_slice = ldx == ldy && d >= (long)c * 2 && d + (long)c * 2 <= (long)ldx * 2;   // same pixel grid, other channels
+    CFT_REQUIRE(disjoint_mem || disjoint_slice, "cft_bottleneck: output overlaps the input (halo reads forbid in-place)");
+  }
+  BneckParams p;
+  p.x = (const unsigned char*)x; p.w1 = (const unsigned char*)w1; p.w2 = (const unsigned char*)w2;
+  p.b1 = b1; p.b2 = b2; p.y = (unsigned char*)y;
+  p.ldx = ldx; p.xoff = xoff; p.ldy = ldy; p.yoff = yoff; p.kpad1 = kpad1; p.kpad2 = kpad2;
+  p.H = H; p.W = W; p.tiles_x = (W + 31) / 32; p.bands = (H + 7) / 8; p.shortcut = shortcut ? 1 : 0;
+  constexpr int smem_bytes = 9 * 64 * 128 + 22 * 16 * 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((bottleneck_kernel<4>), dim3(B * p.bands), dim3(512), smem_bytes, as_stream(stream), p);
+  return cft_check_launch("bottleneck_kernel");
+}

@@ -163,6 +163,12 @@ class Bottleneck(nn.Module):
 
     def forward(self, x, out=None):
         x = resolve(x)
+        if x.is_cuda and not self.training:
+            a1, a2 = _act_code(self.cv1.act), _act_code(self.cv2.act)
+            pk1, pk2 = self.cv1._packed(x.dtype, x.device), self.cv2._packed(x.dtype, x.device)
+            aliased = out is not None and out.data_ptr() == x.data_ptr()   # in-place: the fused kernel reads a halo of x
+            if ops.bottleneck_fusable(x, pk1, pk2, a1, a2) and not aliased:
+                return ops.bottleneck(x, pk1, pk2, self.add, out=out)      # 64-channel stage: one kernel, no hidden tensor
         return self.cv2(self.cv1(x), residual=x if self.add else None, out=out)
 
 

@@ -170,6 +170,42 @@ def conv2d(x, pk, act, residual=None, out=None, out_dtype=None):
     return out
 
 
+def bottleneck_fusable(x, pk1, pk2, act1, act2):
+    """True when ``bottleneck`` below can run as the single cft_bottleneck kernel."""
+    return (x.dtype == torch.bfloat16 and act1 == ACT_SILU and act2 == ACT_SILU
+            and pk1.k == 1 and pk1.s == 1 and pk2.k == 3 and pk2.s == 1
+            and pk1.cin == pk1.n == pk2.cin == pk2.n == 64 and x.shape[1] == 64)
+
+
+def bottleneck(x, pk1, pk2, shortcut, out=None):
+    """x (+) SiLU(conv3x3(SiLU(conv1x1(x)))) for 64 channels in one kernel (cft_bottleneck); ``out`` must not
+    overlap ``x`` (a disjoint channel slice of the same buffer is fine)."""
+    _require_cuda(x, "bottleneck")
+    x, ldx = as_nhwc(x)
+    B, C, H, W = x.shape
+    if out is None:
+        out = new_nhwc(B, H, W, C, x.dtype, x.device)
+    if tuple(out.shape) != (B, C, H, W):
+        raise ValueError(f"bottleneck: out has shape {tuple(out.shape)}, expected {(B, C, H, W)}")
+    ldy = _view_ld(out, "bottleneck out")
+    lib = _lib.load()
+    args = (x.data_ptr(), ldx, 0, pk1.w.data_ptr(), pk1.kpad, pk1.bias.data_ptr() if pk1.bias is not None else None,
+            pk2.w.data_ptr(), pk2.kpad, pk2.bias.data_ptr() if pk2.bias is not None else None,
+            out.data_ptr(), ldy, 0, B, H, W, C, 1 if shortcut else 0, _stream())
+    if _launch_log is None:
+        st = lib.cft_bottleneck(*args)
+    else:   # counted with the GEMM family: both convolutions' FLOPs, one launch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        st = lib.cft_bottleneck(*args)
+        e1.record()
+        rows = B * H * W
+        abytes = rows * C * 2 * (3 if shortcut else 2) + (pk1.w.numel() + pk2.w.numel()) * 2
+        _launch_log.append((f"conv_bneck_c{C}_K{pk1.kpad}+{pk2.kpad}", rows * (pk1.flops_per_row + pk2.flops_per_row), e0, e1, abytes))
+    _lib.check(st, "cft_bottleneck")
+    return out
+
+
 def linear(x, pk, act=ACT_NONE, residual=None, out=None, out_dtype=None):
     """x [rows, K] (row stride >= K) -> [rows, pk.n]; nn.Linear(+bias)(+act)(+residual)."""
     _require_cuda(x, "linear")
