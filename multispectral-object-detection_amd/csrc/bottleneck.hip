@@ -15,6 +15,8 @@
 // Products, 32-wide k chunks, their order and every rounding are those of the two-launch path: bit-identical.
 #include "cft_common.h"
 
+extern int g_conv_variant;   // conv_gemm.hip (cft_set_conv_variant)
+
 struct BneckParams {
   const unsigned char* x;    // bf16 NHWC, ldx channels per pixel, slice offset xoff
   const unsigned char* w1;   // bf16 [C][kpad1]
@@ -26,7 +28,8 @@ struct BneckParams {
   int H, W, tiles_x, bands, shortcut;
 };
 
-template <int NT>
+// ABL (timing probes only, results wrong): 1 = no phase-1 MFMAs/SiLU (zeros), 2 = no phase-2 MFMAs, 4 = no epilogue
+template <int NT, int ABL = 0>
 __global__ void __launch_bounds__(512) bottleneck_kernel(const BneckParams p) {
   static_assert(NT == 4, "the LDS layout below is for 64 channels (128-byte pixel rows)");
   constexpr int C = NT * 16, TW = 32, TH = 8, PW = TW + 2, PH = TH + 2;
@@ -47,23 +50,28 @@ __global__ void __launch_bounds__(512) bottleneck_kernel(const BneckParams p) {
   const long img_pix = (long)b * p.H * p.W;
 
   // 3x3 weights -> LDS, per tap a [C][128 B] tile, slot = k-granule ^ (row & 7)
-  for (int idx = tid; idx < 9 * C * 8; idx += 512) {
+#pragma unroll
+  for (int k = 0; k < 9 * C * 8 / 512; ++k) {   // 9 independent 16-B loads per thread, then the LDS writes
+    const int idx = tid + k * 512;
     const int tap = idx / (C * 8);
     const int r = idx - tap * (C * 8);
     const int n = r >> 3, s = r & 7, g = s ^ (n & 7);
     *reinterpret_cast<gran_t*>(sW2 + tap * (C * 128) + n * 128 + (s << 4)) =
         *reinterpret_cast<const gran_t*>(p.w2 + ((long)n * p.kpad2 + tap * C + g * 8) * 2);
   }
-  // 1x1 weights: B fragments in registers (lane: row n = j*16 + lrow, k = ks*32 + lgrp*8 ..)
+  // 1x1 weights: phase 1 runs transposed (t^T = W1 x^T), so W1 is the ROW operand: lane (row n = j*16 + lrow,
+  // k = ks*32 + lgrp*8 ..) and the accumulator of lane (pixel lrow, group lgrp) holds 4 CONSECUTIVE channels
+  // j*16 + lgrp*4 + e of one pixel - one 8-byte LDS write instead of four scattered 2-byte ones.
   gran_t w1f[NT][2];
-  float b1v[NT], b2v[NT];
+  float b1v[NT][4], b2v[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = j * 16 + lrow;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
       w1f[j][ks] = *reinterpret_cast<const gran_t*>(p.w1 + ((long)n * p.kpad1 + ks * 32 + lgrp * 8) * 2);
-    b1v[j] = p.b1 != nullptr ? p.b1[n] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b1v[j][e] = p.b1 != nullptr ? p.b1[j * 16 + lgrp * 4 + e] : 0.0f;
     b2v[j] = p.b2 != nullptr ? p.b2[n] : 0.0f;
   }
   float* stage = reinterpret_cast<float*>(sT) + wave * (16 * SLD);
@@ -99,25 +107,29 @@ __global__ void __launch_bounds__(512) bottleneck_kernel(const BneckParams p) {
         for (int j = 0; j < NT; ++j) {
           acc1[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) acc1[j] = mma_granule<uint16_t>(a1[it][ks], w1f[j][ks], acc1[j]);
+          for (int ks = 0; ks < 2; ++ks)
+            if constexpr (!(ABL & 1)) acc1[j] = mma_granule<uint16_t>(w1f[j][ks], a1[it][ks], acc1[j]);
         }
+        // this lane's pixel: patch row q (the pixel whose operands it fetched); outside the image t = +0
+        const int q = rt * 16 + lrow;
+        const int py = q / PW, px = q - py * PW;
+        const int zy = y0 - 1 + py, zx = x0 - 1 + px;
+        const bool inside = q < NPIX && (unsigned)zy < (unsigned)p.H && (unsigned)zx < (unsigned)p.W;
+        const uint32_t keep = inside ? 0xffffffffu : 0u;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int q = rt * 16 + lgrp * 4 + e;
-          const int py = q / PW, px = q - py * PW;
-          const int zy = y0 - 1 + py, zx = x0 - 1 + px;
-          const bool inside = q < NPIX && (unsigned)zy < (unsigned)p.H && (unsigned)zx < (unsigned)p.W;
+        for (int j = 0; j < NT; ++j) {
+          float v[4];
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const int n = j * 16 + lrow;
-            const float v = inside ? apply_act<CFT_ACT_SILU>(acc1[j][e] + b1v[j]) : 0.0f;
-            *reinterpret_cast<uint16_t*>(sT + q * 128 + ((((n >> 3) ^ (q & 7)) << 4) | ((n & 7) << 1))) =
-                (uint16_t)(pack_bf16x2(v, 0.0f) & 0xffffu);
-          }
+          for (int e = 0; e < 4; ++e) v[e] = (ABL & 1) ? 0.0f : apply_act<CFT_ACT_SILU>(acc1[j][e] + b1v[j][e]);
+          const int n0 = j * 16 + lgrp * 4;   // first of this lane's 4 channels
+          uint2 w;
+          w.x = pack_bf16x2(v[0], v[1]) & keep;
+          w.y = pack_bf16x2(v[2], v[3]) & keep;
+          *reinterpret_cast<uint2*>(sT + q * 128 + ((((n0 >> 3) ^ (q & 7)) << 4) | ((n0 & 7) << 1))) = w;
         }
       }
     }
-    __syncthreads();   // t patch (and, the first time, the 3x3 weights) complete
+    lds_barrier();   // t patch (and, the first time, the 3x3 weights) complete
 
     // requests that land under phase 2: next tile's phase-1 operands, this tile's shortcut vectors
     if (tx + 1 < p.tiles_x) BNECK_FETCH(tx + 1)
@@ -163,12 +175,21 @@ __global__ void __launch_bounds__(512) bottleneck_kernel(const BneckParams p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = mma_granule<uint16_t>(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < NT; ++j) {
+            if constexpr (ABL & 2) { asm volatile("" ::"v"(af[i]), "v"(bf[j])); }
+            else acc[i][j] = mma_granule<uint16_t>(af[i], bf[j], acc[i][j]);
+          }
       }
     }
-    __syncthreads();   // every wave is done with the t patch before the strips overwrite it
+    lds_barrier();   // every wave is done with the t patch before the strips overwrite it
 
     // ---- epilogue: bias + SiLU -> strip -> (+ shortcut) -> bf16 rows
+    if constexpr (ABL & 4) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -201,7 +222,7 @@ __global__ void __launch_bounds__(512) bottleneck_kernel(const BneckParams p) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __syncthreads();   // strips are dead before the next t patch is written
+    lds_barrier();   // strips are dead before the next t patch is written
   }
 #undef BNECK_FETCH
 }
@@ -234,8 +255,20 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<4, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     attr_done = true;
   }
-  hipLaunchKernelGGL((bottleneck_kernel<4>), dim3(B * p.bands), dim3(512), smem_bytes, as_stream(stream), p);
+  const dim3 grid(B * p.bands), block(512);
+  hipStream_t s = as_stream(stream);
+  switch (g_conv_variant) {   // timing probes (tools/bneck_bench.py)
+    case 901: hipLaunchKernelGGL((bottleneck_kernel<4, 1>), grid, block, smem_bytes, s, p); break;
+    case 902: hipLaunchKernelGGL((bottleneck_kernel<4, 2>), grid, block, smem_bytes, s, p); break;
+    case 904: hipLaunchKernelGGL((bottleneck_kernel<4, 4>), grid, block, smem_bytes, s, p); break;
+    case 907: hipLaunchKernelGGL((bottleneck_kernel<4, 7>), grid, block, smem_bytes, s, p); break;
+    default: hipLaunchKernelGGL((bottleneck_kernel<4>), grid, block, smem_bytes, s, p); break;
+  }
   return cft_check_launch("bottleneck_kernel");
 }

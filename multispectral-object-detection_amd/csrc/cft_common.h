@@ -71,6 +71,13 @@ __device__ __forceinline__ f32x4_t mma_granule<float>(const gran_t& a, const gra
   return c;
 }
 
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the wave's outstanding
+// global loads/stores (s_waitcnt vmcnt(0)), so prefetched operands stay in flight and stores retire under the next
+// phase.  Use it where the data handed over between waves lives in LDS.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Fused epilogue activations (one instantiation per activation, selected uniformly per launch).
 template <int ACT>
 __device__ __forceinline__ float apply_act(float v) {

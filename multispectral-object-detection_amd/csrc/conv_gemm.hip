@@ -366,7 +366,7 @@ static void set_magic(int d, uint32_t& mul, uint32_t& sh) {
 }
 
 // Tile variants.  0 = automatic choice; the others force one configuration (tuning / A-B tests).
-static int g_conv_variant = 0;
+int g_conv_variant = 0;   // also read by bottleneck.hip (ablation probes 9xx)
 extern "C" int cft_set_conv_variant(int v) {
   const int old = g_conv_variant;
   g_conv_variant = v;

@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(512) focus_conv_kernel(const FocusConvParams p
       o[1] = Elem<uint16_t>::pack(v + 8);
     }
     if (tid == PH * PW) *reinterpret_cast<gran_t*>(sZ + ZERO_OFF) = gran_t{0u, 0u, 0u, 0u};
-    __syncthreads();
+    lds_barrier();
     if (tx + 1 < p.tiles_x) FOCUS_FETCH(tx + 1)   // lands under the MFMAs and the epilogue of this tile
 
     // ---- (b) 32 pixels x N channels per wave
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(512) focus_conv_kernel(const FocusConvParams p
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = mma_granule<uint16_t>(af[i], bf[j], acc[i][j]);
     }
-    __syncthreads();   // every wave is done with the patch before the strips overwrite it
+    lds_barrier();   // every wave is done with the patch before the strips overwrite it
 
     // ---- (c) bias + activation -> strip -> bf16 rows
 #pragma unroll
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(512) focus_conv_kernel(const FocusConvParams p
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __syncthreads();   // strips are dead before the next patch is written
+    lds_barrier();   // strips are dead before the next patch is written
   }
 #undef FOCUS_FETCH
 }
