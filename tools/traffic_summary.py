@@ -19,6 +19,7 @@ for c in tot:
             tot[c][k] += float(row["Counter_Value"]) * 1024.0        # counters are in KiB
             if c == "FETCH_SIZE":
                 calls[k] += 1
+GEMM_FAMILY = ("conv_gemm", "focus_conv", "bottleneck_kernel")   # the implicit-GEMM kernels bench.py times as one family
 focus = [k for k in calls if "focus_conv" in k or "focus_s2d" in k]
 n_fwd = calls[focus[0]] / 2 if focus else 1          # two Focus launches per forward
 kern = {}
@@ -26,7 +27,7 @@ for k in sorted(calls, key=lambda k: -(2 * tot["FETCH_SIZE"][k] + tot["WRITE_SIZ
     kern[k] = {"launches_per_forward": calls[k] / n_fwd,
                "hbm_read_bytes": 2.0 * tot["FETCH_SIZE"][k] / n_fwd,     # gfx950: FETCH_SIZE counts 64 B per 128-B request
                "hbm_write_bytes": tot["WRITE_SIZE"][k] / n_fwd}
-gemm = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for k, v in kern.items() if "conv_gemm" in k or "focus_conv" in k)   # the GEMM family incl. the dedicated Focus kernel
+gemm = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for k, v in kern.items() if any(t in k for t in GEMM_FAMILY))
 allb = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in kern.values())
 res = {"config": meta.get("config", "cfg3"), "batch": int(meta.get("batch", 64)), "size": int(meta.get("size", 640)),
        "dtype": meta.get("dtype", "bf16"), "forwards_profiled": n_fwd, "gemm_bytes_per_forward": gemm,
