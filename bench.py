@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="image pairs per GPU")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--no-concat-plan", action="store_true", help="A/B: let Concat copy all its sources")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -153,6 +154,7 @@ def main():
     model.load_state_dict(sd)
     model = model.to(dev).fuse().set_compute_dtype(dtype)   # deployed form: BN folded (attempt_load does .fuse())
     model.overlap_streams = not args.no_overlap
+    model.plan_concats = not args.no_concat_plan
     rgb, ir = seeded_inputs(args.batch, args.size, args.size, seed=rank)
     rgb, ir = rgb.to(dev), ir.to(dev)
 

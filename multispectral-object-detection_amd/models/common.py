@@ -190,7 +190,7 @@ class C3(_Packed):
         w2, b2 = _folded(self.cv2)
         return ops.pack_conv(torch.cat([w1, w2], 0), torch.cat([b1, b2], 0), dtype, device=device)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         x = resolve(x)
         c_ = self.cv1.conv.out_channels
         if _act_code(self.cv1.act) != _act_code(self.cv2.act):
@@ -201,7 +201,7 @@ class C3(_Packed):
         n = len(self.m)
         for j, blk in enumerate(self.m):
             y = blk(y, out=head if j == n - 1 else None)
-        return self.cv3(cat)
+        return self.cv3(cat, out=out)
 
 
 class SPP(nn.Module):
@@ -268,20 +268,28 @@ class Concat(nn.Module):
         super().__init__()
         self.d = dimension
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """``out``: a pre-allocated concat buffer (Model's concat plan); sources that their producer already wrote
+        into their slice of it are not copied again."""
         if self.d != 1:
             raise NotImplementedError("Concat is implemented along channels only")
         shapes = [t.shape for t in x]
         B, _, H, W = shapes[0]
         first = x[0].x if isinstance(x[0], PendingUpsample) else resolve(x[0])
-        out = ops.new_nhwc(B, H, W, sum(s[1] for s in shapes), first.dtype, first.device)
+        total = sum(s[1] for s in shapes)
+        if out is None:
+            out = ops.new_nhwc(B, H, W, total, first.dtype, first.device)
+        elif tuple(out.shape) != (B, total, H, W):
+            raise ValueError(f"Concat: planned buffer {tuple(out.shape)} does not match the inputs {(B, total, H, W)}")
         off = 0
         for t, s in zip(x, shapes):
             dst = out[:, off:off + s[1]]
             if isinstance(t, PendingUpsample):
                 ops.copy_channels(t.x, dst, t.up)
             else:
-                ops.copy_channels(resolve(t), dst, 0)
+                t = resolve(t)
+                if not (t.data_ptr() == dst.data_ptr() and t.stride() == dst.stride()):   # else: already in place
+                    ops.copy_channels(t, dst, 0)
             off += s[1]
         return out
 
@@ -293,8 +301,8 @@ class Add(nn.Module):
         super().__init__()
         self.arg = arg
 
-    def forward(self, x):
-        return ops.add(resolve(x[0]), resolve(x[1]))
+    def forward(self, x, out=None):
+        return ops.add(resolve(x[0]), resolve(x[1]), out=out)
 
 
 class Add2(nn.Module):

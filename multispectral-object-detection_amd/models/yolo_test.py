@@ -227,6 +227,81 @@ class Model(nn.Module):
             lanes.append(lane)
         return lanes
 
+    # ---- concat plan: producers write straight into their slice of the consumer's concat buffer --------------
+    def concat_plan(self):
+        """{producer layer index: (concat layer index, channel offset, channels, total channels)} for every Concat
+        source that is a Conv / C3 / Add (they take ``out=``); such a producer's output tensor then IS a channel
+        slice of the concat buffer and ``Concat`` skips its copy.  Upsample sources stay deferred copies."""
+        plan = self.__dict__.get("_concat_plan")
+        if plan is not None:
+            return plan
+        layers = list(self.model)
+        memo = {}
+
+        def cout(i):
+            if i in memo:
+                return memo[i]
+            m, f = layers[i], layers[i].f
+            src = (lambda j: i + j if j < 0 else j)
+            if isinstance(m, Focus):
+                c = m.conv.conv.out_channels
+            elif type(m) is Conv:
+                c = m.conv.out_channels
+            elif isinstance(m, C3):
+                c = m.cv3.conv.out_channels
+            elif isinstance(m, SPP):
+                c = m.cv2.conv.out_channels
+            elif isinstance(m, Concat):
+                c = sum(cout(src(j)) for j in f)
+            elif isinstance(m, (Add, Add2)):
+                c = cout(src(f[0]))
+            elif isinstance(m, nn.Upsample) and isinstance(f, int):
+                c = cout(src(f))
+            else:
+                c = None                      # GPT tuples, Detect, Sequentials: never a planned source
+            memo[i] = c
+            return c
+
+        plan = {}
+        try:
+            for i, m in enumerate(layers):
+                if not isinstance(m, Concat) or isinstance(m.f, int):
+                    continue
+                srcs = [i + j if j < 0 else j for j in m.f]
+                chans = [cout(j) for j in srcs]
+                if any(c is None for c in chans):
+                    continue
+                off = 0
+                for j, c in zip(srcs, chans):
+                    if (type(layers[j]) is Conv or isinstance(layers[j], (C3, Add))) and j not in plan and layers[j].f != -4:
+                        plan[j] = (i, off, c, sum(chans))
+                    off += c
+        except Exception:                     # foreign module graph: no plan, Concat copies as before
+            plan = {}
+        self.__dict__["_concat_plan"] = plan
+        return plan
+
+    def _run_layer(self, m, x, x2, cbufs):
+        if m.f == -4:
+            return m(x2)
+        tgt = self.concat_plan().get(m.i) if cbufs is not None else None
+        if tgt is not None:
+            cidx, off, c, total = tgt
+            t = resolve(x[0] if isinstance(x, (list, tuple)) else x)
+            if isinstance(t, torch.Tensor) and t.is_cuda and t.dim() == 4:
+                B, _, H, W = t.shape
+                if type(m) is Conv:
+                    k, s_ = m.conv.kernel_size[0], m.conv.stride[0]
+                    H, W = (H + 2 * (k // 2) - k) // s_ + 1, (W + 2 * (k // 2) - k) // s_ + 1
+                buf = cbufs.get(cidx)
+                if buf is None:
+                    buf = cbufs[cidx] = ops.new_nhwc(B, H, W, total, t.dtype, t.device)
+                if tuple(buf.shape) == (B, total, H, W):
+                    return m(x, out=buf[:, off:off + c])
+        if cbufs is not None and isinstance(m, Concat) and m.i in cbufs:
+            return m(x, out=cbufs[m.i])
+        return m(x)
+
     def forward_once(self, x, x2, profile=False):
         """Graph walk of reference models/yolo_test.py:235-272: ``f == -1`` previous output, int /
         list = saved outputs, ``f == -4`` = this layer consumes the IR image ``x2``.
@@ -237,12 +312,13 @@ class Model(nn.Module):
         and stays referenced in ``y`` until the walk ends, so the caching allocator cannot recycle it
         under a kernel of the other stream."""
         lanes = self.stream_lanes() if (self.overlap_streams and x.is_cuda) else None
+        cbufs = {} if (x.is_cuda and self.__dict__.get("plan_concats", True)) else None   # planned concat buffers of this walk
         if lanes is None or 1 not in lanes:
             y = []
             for m in self.model:
                 if m.f != -1 and m.f != -4:
                     x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
-                x = m(x2) if m.f == -4 else m(x)
+                x = self._run_layer(m, x, x2, cbufs)
                 y.append(x if m.i in self.save else None)
             return x
         main = torch.cuda.current_stream(x.device)
@@ -261,7 +337,7 @@ class Model(nn.Module):
             if f != -1 and f != -4:
                 x = y[f] if isinstance(f, int) else [x if j == -1 else y[j] for j in f]
             with torch.cuda.stream(streams[lane]):
-                x = m(x2) if f == -4 else m(x)
+                x = self._run_layer(m, x, x2, cbufs)
             keep.append(x)                           # keep every output alive until both lanes have joined
             y.append(x if m.i in self.save else None)
         main.wait_stream(side)                       # join

@@ -179,3 +179,20 @@ def test_stream_lanes_follow_the_ir_backbone():
             assert lanes[i] == 0
     add = Model(configs.named_config("cfg1")).stream_lanes()
     assert add[:10] == [0] * 10 and add[10:20] == [1] * 10 and set(add[20:]) == {0}
+
+
+def test_concat_plan_routes_producers_into_concat_buffers():
+    """Head Concats: Conv / Add sources write straight into their slice of the concat buffer (no copy);
+    Upsample sources stay deferred copies.  Offsets follow the reference's torch.cat order (common.py:217-219)."""
+    from msod_amd.models.configs import named_config
+    from msod_amd.models.yolo_test import Model
+    m = Model(named_config("cfg3"))
+    plan = m.concat_plan()
+    concats = [i for i, l in enumerate(m.model) if type(l).__name__ == "Concat"]
+    assert len(concats) == 4 and len(plan) == 6
+    for prod, (cidx, off, c, total) in plan.items():
+        srcs = [cidx + j if j < 0 else j for j in m.model[cidx].f]
+        assert prod in srcs and type(m.model[prod]).__name__ in ("Conv", "Add", "C3")
+        assert off == (0 if srcs.index(prod) == 0 else total - c) and 0 < c < total
+    ups = [s for cidx in concats for s in (cidx + j if j < 0 else j for j in m.model[cidx].f) if type(m.model[s]).__name__ == "Upsample"]
+    assert ups and not any(u in plan for u in ups)
