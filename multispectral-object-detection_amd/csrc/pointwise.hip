@@ -160,6 +160,57 @@ __global__ void __launch_bounds__(256) spp_maxpool_kernel(unsigned char* buf, in
   }
 }
 
+// Fast path for the SPP the networks use (k, 2k-1, 3k-2, e.g. 5/9/13): max-pooling composes exactly,
+// mp(2r) = mp(r) o mp(r) and mp(3r) = mp(r) o mp(2r) (windows clipped to the map, -inf padding), so the three
+// outputs are a chain of three identical separable radius-r passes.  One workgroup owns G consecutive 16-byte
+// channel granules of one image (64-byte runs per pixel for G = 4 - the generic kernel above touches 16 B per
+// 128-B line), two LDS planes ping-pong: A --rows--> B --columns--> A (+ store), three times.
+template <typename T>
+__global__ void __launch_bounds__(512) spp_chain_kernel(unsigned char* buf, int H, int W, int C, int ld, int r, int G) {
+  constexpr int GE = Elem<T>::GE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int HW = H * W, n = HW * G;
+  gran_t* A = reinterpret_cast<gran_t*>(smem);
+  gran_t* Bp = A + n;
+  const int groups = (C / GE) / G;
+  const int b = blockIdx.x / groups, g0 = (blockIdx.x - b * groups) * G;
+  unsigned char* base = buf + ((long)b * HW * ld + (long)g0 * GE) * sizeof(T);
+  const long pix_stride = (long)ld * sizeof(T);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int px = i / G, g = i - px * G;
+    A[i] = *reinterpret_cast<const gran_t*>(base + px * pix_stride + g * 16);
+  }
+  __syncthreads();
+  for (int k = 0; k < 3; ++k) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {      // rows: A -> Bp
+      const int px = i / G;
+      const int x = px % W;
+      float m[GE];
+      Elem<T>::unpack(A[i], m);
+      for (int d = 1; d <= r; ++d) {
+        if (x - d >= 0) gmax<T>(m, A[i - d * G]);
+        if (x + d < W) gmax<T>(m, A[i + d * G]);
+      }
+      Bp[i] = Elem<T>::pack(m);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {      // columns: Bp -> A, and out
+      const int px = i / G, g = i - px * G;
+      const int y = px / W;
+      float m[GE];
+      Elem<T>::unpack(Bp[i], m);
+      for (int d = 1; d <= r; ++d) {
+        if (y - d >= 0) gmax<T>(m, Bp[i - d * W * G]);
+        if (y + d < H) gmax<T>(m, Bp[i + d * W * G]);
+      }
+      const gran_t o = Elem<T>::pack(m);
+      A[i] = o;
+      *reinterpret_cast<gran_t*>(base + px * pix_stride + ((long)(k + 1) * C * sizeof(T)) + g * 16) = o;
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int cft_spp_maxpool(void* buf, int B, int H, int W, int C, int ld, int k1, int k2, int k3,
                                int dtype, void* stream) {
   CFT_REQUIRE(buf != nullptr, "cft_spp_maxpool: null pointer");
@@ -167,17 +218,35 @@ extern "C" int cft_spp_maxpool(void* buf, int B, int H, int W, int C, int ld, in
   const int ge = dtype == CFT_BF16 ? 8 : 4;
   CFT_REQUIRE(C % ge == 0 && ld % ge == 0 && ld >= 4 * C, "cft_spp_maxpool: C/ld not granule aligned or ld < 4C");
   CFT_REQUIRE((k1 & 1) && (k2 & 1) && (k3 & 1) && k1 <= k2 && k2 <= k3 && k3 <= 13 && k1 >= 1, "cft_spp_maxpool: kernel sizes must be odd, ascending, <= 13");
+  const int r1 = k1 / 2, r2 = k2 / 2, r3 = k3 / 2, gpc = C / ge;
+  if (r1 >= 1 && r2 == 2 * r1 && r3 == 3 * r1 && (size_t)2 * H * W * 16 <= 160 * 1024) {   // chained passes (5/9/13)
+    int G = 1;
+    for (int g = 4; g > 1; g >>= 1)
+      if (gpc % g == 0 && (size_t)2 * H * W * g * 16 <= 64 * 1024) { G = g; break; }
+    const size_t smem = (size_t)2 * H * W * G * 16;
+    const int grid = B * (gpc / G);
+    if (dtype == CFT_BF16) {
+      static bool done = false;
+      if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spp_chain_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+      hipLaunchKernelGGL(spp_chain_kernel<uint16_t>, dim3(grid), dim3(512), smem, as_stream(stream), (unsigned char*)buf, H, W, C, ld, r1, G);
+    } else {
+      static bool done = false;
+      if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spp_chain_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+      hipLaunchKernelGGL(spp_chain_kernel<float>, dim3(grid), dim3(512), smem, as_stream(stream), (unsigned char*)buf, H, W, C, ld, r1, G);
+    }
+    return cft_check_launch("spp_chain_kernel");
+  }
   const size_t smem = (size_t)4 * H * W * 16;
   CFT_REQUIRE(smem <= 160 * 1024, "cft_spp_maxpool: feature map too large for the LDS plane (H*W <= 2560)");
-  const int grid = B * (C / ge);
+  const int grid = B * gpc;
   if (dtype == CFT_BF16) {
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spp_maxpool_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-    hipLaunchKernelGGL(spp_maxpool_kernel<uint16_t>, dim3(grid), dim3(256), smem, as_stream(stream), (unsigned char*)buf, H, W, C, ld, k1 / 2, k2 / 2, k3 / 2);
+    hipLaunchKernelGGL(spp_maxpool_kernel<uint16_t>, dim3(grid), dim3(256), smem, as_stream(stream), (unsigned char*)buf, H, W, C, ld, r1, r2, r3);
   } else {
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spp_maxpool_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-    hipLaunchKernelGGL(spp_maxpool_kernel<float>, dim3(grid), dim3(256), smem, as_stream(stream), (unsigned char*)buf, H, W, C, ld, k1 / 2, k2 / 2, k3 / 2);
+    hipLaunchKernelGGL(spp_maxpool_kernel<float>, dim3(grid), dim3(256), smem, as_stream(stream), (unsigned char*)buf, H, W, C, ld, r1, r2, r3);
   }
   return cft_check_launch("spp_maxpool_kernel");
 }

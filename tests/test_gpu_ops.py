@@ -364,3 +364,22 @@ def test_bottleneck_fused_is_bit_identical(dev, shortcut, hw):
         ops.bottleneck(xin, pk1, pk2, shortcut, out=xin)         # in-place is refused (halo reads)
     ref = O.bottleneck(sd, "m.", x, shortcut)
     assert rel_err(to_cpu_f32(fused), ref) < 2 * tol(dtype)   # two bf16 roundings (hidden tensor, output)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("ks", [(5, 9, 13), (3, 5, 7), (3, 5, 9), (5, 7, 13)])
+def test_spp_maxpool_kernel_sizes(dev, dtype, ks):
+    """Chained fast path (k, 2k-1, 3k-2) and the generic kernel: both exact against F.max_pool2d, on a
+    64-channel map (four-granule workgroups) that is not square."""
+    from msod_amd import ops
+    H, W, C = 20, 12, 64
+    x = _q(_rnd(3, C, H, W, seed=70), dtype)
+    buf = torch.zeros(3, 4 * C, H, W)
+    buf[:, :C] = x
+    d = to_dev_nhwc(buf, dev, dtype)
+    ops.spp_maxpool(d, C, ks)
+    torch.cuda.synchronize()
+    got = to_cpu_f32(d)
+    for i, k in enumerate(ks):
+        assert torch.equal(got[:, (i + 1) * C:(i + 2) * C], F.max_pool2d(x, k, 1, k // 2)), f"k={k}"
+    assert torch.equal(got[:, :C], x)
