@@ -1,12 +1,15 @@
 // Multi-head self-attention core of the CFT block for gfx950: O = softmax(Q K^T / sqrt(dk)) V over a
 // fixed T = 128 tokens (64 RGB + 64 IR cells; reference models/common.py:491-510).  One 256-thread
-// workgroup per (image, head); wave w owns query rows [32w, 32w+32).  The whole 128x128 score tile
-// lives in registers (no KV loop, no online softmax needed).
-//   S = Q K^T : Q fragments straight from global (read once), K staged in LDS, MFMA 16x16.
-//   softmax   : row max / sum via in-lane reduction over the 8 column tiles + 4 xor-shuffles.
-//   O = P V   : P (unnormalised exp, compute dtype) to a wave-private LDS strip that aliases the K
-//               tile; V is staged TRANSPOSED in <= 64-column chunks so both MFMA operands are
-//               k(token)-contiguous 16-byte granules.  O is scaled by 1/rowsum in fp32 at the end.
+// workgroup per (image, head); wave w owns queries [32w, 32w+32).  The whole 128x128 score tile lives in
+// registers (no KV loop, no online softmax), and it is computed TRANSPOSED:
+//   S^T = K Q^T : K fragments (row operand) from LDS, Q fragments (column operand) straight from global; a lane
+//                 then holds, for ONE query (its column), 4 consecutive keys of each of the 8 key tiles;
+//   softmax     : per query = in-lane over 32 values + two xor-shuffles across the four lane groups;
+//   O^T = V^T P^T: the exponentials never leave the registers - the 8 values a lane holds for a 32-key chunk
+//                 (two key tiles) ARE its column-operand fragment, because the MFMA reduction does not care
+//                 which k index a (lane-group, element) slot stands for as long as both operands agree; the
+//                 V^T fragment reads the matching keys (two 8-byte runs) from the transposed LDS copy of V;
+//   store       : a lane ends up with 4 consecutive head columns of one query -> one 8-byte (bf16) store.
 // Head width arrives padded to dkp (multiple of 4 granules) with zero columns, so no K-tail code.
 #include "cft_common.h"
 
@@ -16,12 +19,13 @@ __global__ void __launch_bounds__(256) attention_kernel(const unsigned char* __r
   constexpr int GE = Elem<T>::GE;
   constexpr int ES = (int)sizeof(T);
   constexpr int T_TOK = 128;
-  constexpr int PS_B = T_TOK * ES + 16;   // P / V^T row stride in bytes (odd number of 16-B slots)
+  constexpr int KT = GE / 4;               // 16-key score tiles per MFMA k chunk (bf16: 2 -> 32 keys, f32: 1 -> 16 keys)
+  constexpr int NCH = 8 / KT;              // k chunks over the 128 keys
+  constexpr int PS_B = T_TOK * ES + 16;    // V^T row stride in bytes (odd number of 16-B slots)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int KS_B = dkp * ES + 16;          // K row stride in bytes
-  const int region0 = T_TOK * (KS_B > PS_B ? KS_B : PS_B);
   unsigned char* sK = smem;
-  unsigned char* sVT = smem + region0;     // [<=64][PS_B]
+  unsigned char* sVT = smem + T_TOK * KS_B;   // [<=64 head columns][PS_B]
 
   const int b = blockIdx.x / heads, head = blockIdx.x % heads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -33,14 +37,37 @@ __global__ void __launch_bounds__(256) attention_kernel(const unsigned char* __r
   const unsigned char* kbase = qbase + (long)heads * dkp * ES;
   const unsigned char* vbase = kbase + (long)heads * dkp * ES;
 
-  // ---- stage K ----
+// V^T of head columns [c0_, c0_ + cw_) -> LDS (2-/4-byte scattered writes; V is read once, coalesced)
+#define ATT_STAGE_VT(c0_, cw_)                                                                             \
+  {                                                                                                        \
+    const int cg_ = (cw_) / GE;                                                                            \
+    for (int i = tid; i < T_TOK * cg_; i += 256) {                                                         \
+      const int t = i / cg_, kg = i - t * cg_;                                                             \
+      const gran_t g = *reinterpret_cast<const gran_t*>(vbase + t * ldq_b + (long)((c0_) + kg * GE) * ES); \
+      if (ES == 2) {                                                                                       \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
+          *reinterpret_cast<uint16_t*>(sVT + (kg * GE + 2 * e) * PS_B + t * 2) = (uint16_t)(g[e] & 0xffffu); \
+          *reinterpret_cast<uint16_t*>(sVT + (kg * GE + 2 * e + 1) * PS_B + t * 2) = (uint16_t)(g[e] >> 16); \
+        }                                                                                                  \
+      } else {                                                                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                      \
+          *reinterpret_cast<uint32_t*>(sVT + (kg * GE + e) * PS_B + t * 4) = g[e];                         \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
+
+  // ---- stage K and the first V^T chunk ----
   for (int i = tid; i < T_TOK * G; i += 256) {
     const int t = i / G, kg = i - t * G;
     *reinterpret_cast<gran_t*>(sK + t * KS_B + kg * 16) = *reinterpret_cast<const gran_t*>(kbase + t * ldq_b + kg * 16);
   }
+  {
+    const int cw0 = dkp < 64 ? dkp : 64;
+    ATT_STAGE_VT(0, cw0)
+  }
   __syncthreads();
 
-  // ---- S = Q K^T ----
+  // ---- S^T = K Q^T: s[i][j][e] = score(query wave*32 + i*16 + lrow, key j*16 + lgrp*4 + e) ----
   f32x4_t s[2][8];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -57,100 +84,91 @@ __global__ void __launch_bounds__(256) attention_kernel(const unsigned char* __r
     for (int j = 0; j < 8; ++j) {
       const gran_t kf = *reinterpret_cast<const gran_t*>(sK + (j * 16 + lrow) * KS_B + kg * 16);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) s[i][j] = mma_granule<T>(qf[i], kf, s[i][j]);
+      for (int i = 0; i < 2; ++i) s[i][j] = mma_granule<T>(kf, qf[i], s[i][j]);
     }
   }
 
-  // ---- softmax over the 128 columns of each row (rows: i*16 + lgrp*4 + e) ----
-  float inv_sum[2][4];
+  // ---- softmax over the 128 keys of this lane's query: 32 values in the lane, the rest in lanes +-16, +-32 ----
+  float inv_sum[2];
+  gran_t pf[2][NCH];   // unnormalised exponentials as MFMA column-operand fragments
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float mx = -INFINITY;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { s[i][j][e] *= scale; mx = fmaxf(mx, s[i][j][e]); }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-      float sum = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float pv = __expf(s[i][j][e] - mx); s[i][j][e] = pv; sum += pv; }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
-      inv_sum[i][e] = 1.0f / sum;
-    }
-
-  __syncthreads();   // every wave is done with K before P overwrites it
-  unsigned char* sP = smem + wave * 32 * PS_B;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+    float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        unsigned char* dst = sP + (i * 16 + lgrp * 4 + e) * PS_B + (j * 16 + lrow) * ES;
-        if (ES == 2) *reinterpret_cast<uint16_t*>(dst) = f32_to_bf16(s[i][j][e]);
-        else *reinterpret_cast<float*>(dst) = s[i][j][e];
-      }
-
-  // ---- O = P V, in chunks of <= 64 head columns ----
-  for (int c0 = 0; c0 < dkp; c0 += 64) {
-    const int cw = (dkp - c0) < 64 ? (dkp - c0) : 64;
-    const int cg = cw / GE;   // granules per token in this chunk
-    __syncthreads();          // previous chunk's V^T fully consumed (and P visible on first pass)
-    for (int i = tid; i < T_TOK * cg; i += 256) {
-      const int t = i / cg, kg = i - t * cg;
-      const gran_t g = *reinterpret_cast<const gran_t*>(vbase + t * ldq_b + (long)(c0 + kg * GE) * ES);
-      if (ES == 2) {
+      for (int e = 0; e < 4; ++e) { s[i][j][e] *= scale; mx = fmaxf(mx, s[i][j][e]); }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          *reinterpret_cast<uint16_t*>(sVT + (kg * GE + 2 * e) * PS_B + t * 2) = (uint16_t)(g[e] & 0xffffu);
-          *reinterpret_cast<uint16_t*>(sVT + (kg * GE + 2 * e + 1) * PS_B + t * 2) = (uint16_t)(g[e] >> 16);
-        }
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float pv = __expf(s[i][j][e] - mx); s[i][j][e] = pv; sum += pv; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    inv_sum[i] = 1.0f / sum;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if constexpr (ES == 2) {
+        pf[i][c] = gran_t{pack_bf16x2(s[i][2 * c][0], s[i][2 * c][1]), pack_bf16x2(s[i][2 * c][2], s[i][2 * c][3]),
+                          pack_bf16x2(s[i][2 * c + 1][0], s[i][2 * c + 1][1]), pack_bf16x2(s[i][2 * c + 1][2], s[i][2 * c + 1][3])};
       } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) *reinterpret_cast<uint32_t*>(sVT + (kg * GE + e) * PS_B + t * 4) = g[e];
+        pf[i][c] = gran_t{__float_as_uint(s[i][c][0]), __float_as_uint(s[i][c][1]), __float_as_uint(s[i][c][2]), __float_as_uint(s[i][c][3])};
       }
     }
-    __syncthreads();
+  }
+
+  // ---- O^T = V^T P^T, in chunks of <= 64 head columns ----
+  for (int c0 = 0; c0 < dkp; c0 += 64) {
+    const int cw = (dkp - c0) < 64 ? (dkp - c0) : 64;
+    if (c0 > 0) {
+      __syncthreads();          // previous chunk's V^T fully consumed
+      ATT_STAGE_VT(c0, cw)
+      __syncthreads();
+    }
     const int ntc = cw >> 4;
     f32x4_t o[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    constexpr int PSTEPS = (T_TOK / GE) / 4;
 #pragma unroll
-    for (int ks = 0; ks < PSTEPS; ++ks) {
-      const int kg = ks * 4 + lgrp;
-      gran_t pf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) pf[i] = *reinterpret_cast<const gran_t*>(sP + (i * 16 + lrow) * PS_B + kg * 16);
+    for (int c = 0; c < NCH; ++c) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (j < ntc) {
-          const gran_t vf = *reinterpret_cast<const gran_t*>(sVT + (j * 16 + lrow) * PS_B + kg * 16);
+          const unsigned char* vrow = sVT + (j * 16 + lrow) * PS_B;
+          gran_t vf;
+          if constexpr (ES == 2) {   // keys (2c)*16 + lgrp*4 .. +3 and (2c+1)*16 + lgrp*4 .. +3: the slots of pf[.][c]
+            const uint2 lo = *reinterpret_cast<const uint2*>(vrow + ((2 * c) * 16 + lgrp * 4) * 2);
+            const uint2 hi = *reinterpret_cast<const uint2*>(vrow + ((2 * c + 1) * 16 + lgrp * 4) * 2);
+            vf = gran_t{lo.x, lo.y, hi.x, hi.y};
+          } else {
+            vf = *reinterpret_cast<const gran_t*>(vrow + (c * 16 + lgrp * 4) * 4);
+          }
 #pragma unroll
-          for (int i = 0; i < 2; ++i) o[i][j] = mma_granule<T>(pf[i], vf, o[i][j]);
+          for (int i = 0; i < 2; ++i) o[i][j] = mma_granule<T>(vf, pf[i][c], o[i][j]);
         }
       }
     }
+    // o[i][j][e] = O(query wave*32 + i*16 + lrow, head column c0 + j*16 + lgrp*4 + e)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (j < ntc) {
+          const int row = wave * 32 + i * 16 + lrow;
+          float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int row = wave * 32 + i * 16 + lgrp * 4 + e;
-            const float v = o[i][j][e] * inv_sum[i][e];
-            unsigned char* dst = out + ((long)b * T_TOK + row) * ldo_b + ((long)head * dkp + c0 + j * 16 + lrow) * ES;
-            if (ES == 2) *reinterpret_cast<uint16_t*>(dst) = f32_to_bf16(v);
-            else *reinterpret_cast<float*>(dst) = v;
-          }
+          for (int e = 0; e < 4; ++e) v[e] = o[i][j][e] * inv_sum[i];
+          unsigned char* dst = out + ((long)b * T_TOK + row) * ldo_b + ((long)head * dkp + c0 + j * 16 + lgrp * 4) * ES;
+          if constexpr (ES == 2) *reinterpret_cast<uint2*>(dst) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          else *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{v[0], v[1], v[2], v[3]};
         }
       }
   }
+#undef ATT_STAGE_VT
 }
 
 extern "C" int cft_attention(const void* qkv, void* out, int B, int heads, int dk, int dkp,
@@ -161,7 +179,7 @@ extern "C" int cft_attention(const void* qkv, void* out, int B, int heads, int d
   const int kstep = dtype == CFT_BF16 ? 32 : 16;
   CFT_REQUIRE(B > 0 && heads > 0 && dk > 0 && dkp >= dk && dkp % kstep == 0 && dkp <= 256, "cft_attention: dkp must be a multiple of 32 (bf16) / 16 (f32), >= dk, <= 256");
   const int ps = 128 * es + 16, ks = dkp * es + 16;
-  const size_t smem = (size_t)128 * (ks > ps ? ks : ps) + (size_t)64 * ps;
+  const size_t smem = (size_t)128 * ks + (size_t)64 * ps;
   CFT_REQUIRE(smem <= 160 * 1024, "cft_attention: head too wide for LDS");
   const float scale = 1.0f / sqrtf((float)dk);
   if (dtype == CFT_BF16) {
