@@ -190,11 +190,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
   constexpr int GE = Elem<T>::GE;
   constexpr int BK = 8 * GE;
   constexpr int RPP = NTHR / 8;  // tile rows staged per pass of the whole workgroup
-  constexpr int A_PER = BM / RPP, B_PER = (BN + RPP - 1) / RPP;   // BN < RPP: only the first BN rows' threads stage B
+  constexpr int A_PER = BM / RPP, B_PER = (BN + RPP - 1) / RPP;   // BN % RPP != 0: the last pass stages only the waves below BN
   constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 16, NT = WN / 16;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   constexpr int ES = (int)sizeof(T);
-  static_assert(BM % RPP == 0 && (BN % RPP == 0 || BN < RPP) && WM % 16 == 0 && WN % 16 == 0, "tile shape");
+  static_assert(BM % RPP == 0 && BN % 8 == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
   unsigned char* sB = smem + 2 * A_BYTES;
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
     }                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < B_PER; ++i) {                                                \
       const int n = n0 + r0 + i * RPP;                                                                 \
-      if (BN < RPP && wave * 8 >= BN) continue; /* wave-uniform: this wave has no B rows */             \
+      if (BN % RPP != 0 && i * RPP + wave * 8 >= BN) continue; /* wave-uniform: no B rows in this pass */ \
       if constexpr (GLDS) {                                                                            \
         const unsigned char* src = (n < p.N) ? p.w + ((long)n * p.Kpad + kglob) * ES : zero_page;      \
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src,                                             \
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
     _Pragma("unroll") for (int i = 0; i < A_PER; ++i)                                                  \
       *reinterpret_cast<gran_t*>(sA + (buf_) * A_BYTES + (r0 + i * RPP) * 128 + swz) = ra[i];          \
     _Pragma("unroll") for (int i = 0; i < B_PER; ++i)                                                  \
-      if (BN >= RPP || r0 < BN)                                                                        \
+      if (BN % RPP == 0 || r0 + i * RPP < BN)                                                          \
         *reinterpret_cast<gran_t*>(sB + (buf_) * B_BYTES + (r0 + i * RPP) * 128 + swz) = rb[i];        \
   }
 
@@ -406,6 +406,12 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
     case 51: return launch_conv<T, 192, 128, 2, 4, true>(p, stream);
     case 60: return launch_conv<T, 128, 256, 4, 4, true>(p, stream);
     case 63: return launch_conv<T, 64, 128, 2, 4, true>(p, stream);
+    case 70: return launch_conv<T, 256, 160, 8, 2, true>(p, stream);   // 80/160-wide tiles: yolov5x / yolov5m channel counts
+    case 71: return launch_conv<T, 256, 160, 4, 2, true>(p, stream);
+    case 72: return launch_conv<T, 128, 160, 4, 2, true>(p, stream);
+    case 73: return launch_conv<T, 256, 80, 4, 1, true>(p, stream);
+    case 74: return launch_conv<T, 256, 80, 8, 1, true>(p, stream);
+    case 75: return launch_conv<T, 128, 80, 4, 1, true>(p, stream);
     case 1627: return launch_conv<T, 256, 256, 4, 4, true, 16>(p, stream);
     case 127: return launch_conv<T, 256, 256, 4, 4, true, 1>(p, stream);
     case 227: return launch_conv<T, 256, 256, 4, 4, true, 2>(p, stream);
@@ -423,6 +429,16 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
     if (tiles(256, 64) >= kCUs) return launch_conv<T, 256, 64, 4, 2, true>(p, stream);
     if (tiles(128, 64) >= kCUs) return launch_conv<T, 128, 64, 2, 2, true>(p, stream);
     return launch_conv<T, 64, 64, 2, 2, true>(p, stream);
+  }
+  if (p.N > 64) {
+    // channel counts that are multiples of 80 / 160 but not of 128 (yolov5x: 80, 160, 320): the 128/256-wide tiles
+    // would compute up to 37 % padding.  128x160 / 128x80 (8 / 4 waves, two+ workgroups per CU) measured -14..-27 %
+    // on those layers; taken only when they cut the padded width by >= 10 %, so 64/128/256-multiples are unaffected.
+    const long p128 = (long)((p.N + 127) / 128) * 128, p256 = (long)((p.N + 255) / 256) * 256;
+    const long cur = (p.N <= 128) ? p128 : ((p256 * 100 <= p128 * 115) ? p256 : p128);
+    const long p160 = (long)((p.N + 159) / 160) * 160, p80 = (long)((p.N + 79) / 80) * 80;
+    if (p160 * 100 <= cur * 90 && p160 <= p80 && tiles(128, 160) >= kCUs / 2) return launch_conv<T, 128, 160, 4, 2, true>(p, stream);
+    if (p80 * 100 <= cur * 90 && p80 < p160 && tiles(128, 80) >= kCUs / 2) return launch_conv<T, 128, 80, 4, 1, true>(p, stream);
   }
   if (p.N <= 128) {
     // 192x128 with 8 waves is the largest 128-wide tile of which TWO workgroups fit a CU (80 KiB LDS each): the

@@ -260,7 +260,7 @@ def test_errors_are_loud(dev):
         ops.conv2d(torch.zeros(1, 8, 4, 4, device=dev, dtype=torch.float16), pk, 0)
 
 
-TILE_VARIANTS = [1, 2, 4, 6, 7, 8, 23, 27, 30, 32, 33, 51, 60, 63]
+TILE_VARIANTS = [1, 2, 4, 6, 7, 8, 23, 27, 30, 32, 33, 51, 60, 63, 70, 71, 72, 73, 74, 75]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])

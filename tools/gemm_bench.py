@@ -34,6 +34,12 @@ SHAPES = [
     ("bneck 3x3 512->512 @20", 64, 20, 20, 512, 512, 3, 1, False, 9),
     ("1x1 1024->1024 @20", 64, 20, 20, 1024, 1024, 1, 1, False, 6),
     ("SPP cv2 1x1 2048->1024 @20", 64, 20, 20, 2048, 1024, 1, 1, False, 2),
+    ("x5 3x3 160->160 @160 +res", 16, 160, 160, 160, 160, 3, 1, True, 0),
+    ("x5 3x3 320->320 @80 +res", 16, 80, 80, 320, 320, 3, 1, True, 0),
+    ("x5 3x3 80->80 @320 +res", 16, 320, 320, 80, 80, 3, 1, True, 0),
+    ("x5 3x3 640->640 @40", 16, 40, 40, 640, 640, 3, 1, False, 0),
+    ("x5 1x1 160->160 @160", 16, 160, 160, 160, 160, 1, 1, False, 0),
+    ("x5 1x1 320->320 @80", 16, 80, 80, 320, 320, 1, 1, False, 0),
     ("GPT qkv 1024->3072 (M=8192)", 1, 1, 8192, 1024, 3072, 1, 1, False, 8),
     ("GPT fc1 1024->4096", 1, 1, 8192, 1024, 4096, 1, 1, False, 8),
     ("GPT fc2 4096->1024", 1, 1, 8192, 4096, 1024, 1, 1, False, 8),
