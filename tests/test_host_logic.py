@@ -116,6 +116,20 @@ def test_bad_arguments_return_error_codes_without_gpu():
     assert st == -1 and b"null pointer" in lib.cft_last_error()
     st = lib.cft_layernorm(1, 1, 1, 1, 4, 6, 1e-5, 0, None)     # C not a multiple of 4; rejected before any launch
     assert st == -1
+    # fused Focus: only 32/48/64/80 output channels, weights packed [n][192], even pointer/strides
+    st = lib.cft_focus_conv(16, 0, 3 * 64 * 64, 64 * 64, 64, 1.0, 16, 192, None, 16, 40, 0, 1, 64, 64, 40, 1, None)
+    assert st == -1 and b"n must be 32, 48, 64 or 80" in lib.cft_last_error()
+    st = lib.cft_focus_conv(16, 0, 3 * 64 * 64, 64 * 64, 64, 1.0, 16, 160, None, 16, 64, 0, 1, 64, 64, 64, 1, None)
+    assert st == -1 and b"[n][192]" in lib.cft_last_error()
+    st = lib.cft_focus_conv(17, 1, 3 * 64 * 64, 64 * 64, 64, 1.0 / 255, 16, 192, None, 16, 64, 0, 1, 64, 64, 64, 1, None)
+    assert st == -1 and b"pixel-pair" in lib.cft_last_error()
+    # fused Bottleneck: 64 channels only, and never in place (it reads a halo of x)
+    st = lib.cft_bottleneck(4096, 128, 0, 16, 128, None, 16, 1152, None, 1 << 20, 128, 0, 1, 8, 8, 128, 1, None)
+    assert st == -1 and b"64 channels" in lib.cft_last_error()
+    st = lib.cft_bottleneck(4096, 64, 0, 16, 64, None, 16, 576, None, 4096, 64, 0, 1, 8, 8, 64, 1, None)
+    assert st == -1 and b"overlaps the input" in lib.cft_last_error()
+    st = lib.cft_bottleneck(4096, 128, 0, 16, 64, None, 16, 576, None, 4096 + 64, 128, 0, 1, 8, 8, 64, 1, None)
+    assert st == -1 and b"overlaps" in lib.cft_last_error()       # slices of one buffer that share channels [32,64)
 
 
 def test_no_cpu_fallback():
