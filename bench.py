@@ -240,7 +240,7 @@ def main():
                          "top_shapes": [{"shape": k, "launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
                                          "ms": round(v[2] * 1e3, 3)} for k, v in top]},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(cfg, {k: v for k, v in model.cpu().state_dict().items()},
                                                 args.size, args.size)
         print(json.dumps(line), flush=True)
