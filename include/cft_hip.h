@@ -14,7 +14,8 @@
  *  - activations are NHWC ("channels-last"): element (b,y,x,c) of a tensor with `ld` channels
  *    per pixel lives at ((b*H + y)*W + x)*ld + off + c, so a tensor may be a channel slice
  *    [off, off+C) of a wider buffer (this is how Concat / C3 / SPP avoid copies);
- *  - dtype codes: CFT_BF16 (bfloat16) or CFT_F32; `dtype` is the compute/activation type;
+ *  - dtype codes: CFT_BF16 (bfloat16), CFT_F16 (IEEE half - the precision the reference's GPU callers use,
+ *    test.py:66-68 `model.half()`) or CFT_F32; `dtype` is the compute/activation type; all three accumulate in fp32;
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default);
  *  - return value: CFT_OK (0) or a negative CFT_E* code; nothing is launched on error.
  */
@@ -25,7 +26,7 @@
 extern "C" {
 #endif
 
-enum { CFT_BF16 = 0, CFT_F32 = 1 };
+enum { CFT_BF16 = 0, CFT_F32 = 1, CFT_F16 = 2 };
 enum { CFT_ACT_NONE = 0, CFT_ACT_SILU = 1, CFT_ACT_GELU = 2 };
 enum {
   CFT_OK = 0,
@@ -63,14 +64,14 @@ int cft_conv2d(const void* x, const void* w, const float* bias, const void* res,
 
 /*
  * Bottleneck as one kernel (models/common.py:99-109 with e = 1.0, the form C3 uses :138):
- *   y = (shortcut ? x : 0) + SiLU(conv3x3(SiLU(conv1x1(x) + b1)) + b2),  c -> c -> c channels, c = 64, bf16.
+ *   y = (shortcut ? x : 0) + SiLU(conv3x3(SiLU(conv1x1(x) + b1)) + b2),  c -> c -> c channels, 16-bit dtype.
  * x, y: NHWC channel slices (ldx/xoff, ldy/yoff) that must not overlap (the kernel reads a halo of x);
  * w1 [c][kpad1] and w2 [c][kpad2] in the cft_conv2d layout (BN folded).  Bit-identical to two cft_conv2d calls
  * (1x1 + SiLU, then 3x3 + SiLU + residual); the hidden tensor never reaches HBM.
  */
 int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, int kpad1, const float* b1,
                    const void* w2, int kpad2, const float* b2, void* y, int ldy, int yoff,
-                   int B, int H, int W, int c, int shortcut, void* stream);
+                   int B, int H, int W, int c, int shortcut, int dtype, void* stream);
 
 /* Tuning knob: force one tile configuration of cft_conv2d (0 = automatic, the default; see
  * csrc/conv_gemm.hip for the table).  Returns the previous value.  Not needed for normal use. */
@@ -95,15 +96,16 @@ int cft_focus_s2d_u8(const unsigned char* in, long stride_b, long stride_c, long
 
 /*
  * Focus in one kernel: the space-to-depth above plus its 3x3 Conv (+ folded BN, + SiLU; models/common.py:168-179
- * with :45-50) straight from the image, bf16 compute, no intermediate tensor.  `in` is the first channel of the
- * stream: float (in_u8 = 0, scale = 1) or unsigned char (in_u8 = 1, scale = 1/255; test.py:106-113), element
- * strides for batch / channel / row, row elements contiguous, pointer and strides multiples of 2 elements.
- * w: bf16 [n][192], k = (kh*3 + kw)*16 + ci, ci < 12 real (the cft_conv2d layout for cin = 16); n in {32,48,64,80};
- * y: bf16 NHWC [B,H/2,W/2] with ldy/yoff.  Bit-identical to cft_focus_s2d(_u8) followed by cft_conv2d.
+ * with :45-50) straight from the image, 16-bit compute (dtype = CFT_BF16 or CFT_F16), no intermediate tensor.
+ * `in` is the first channel of the stream: float (in_kind = 0, scale = 1), unsigned char (in_kind = 1,
+ * scale = 1/255; test.py:106-113) or half (in_kind = 2, the `img.half()` of test.py:107; dtype CFT_F16 only);
+ * element strides for batch / channel / row, row elements contiguous, pointer and strides multiples of 2 elements.
+ * w: dtype [n][192], k = (kh*3 + kw)*16 + ci, ci < 12 real (the cft_conv2d layout for cin = 16); n in {32,48,64,80};
+ * y: dtype NHWC [B,H/2,W/2] with ldy/yoff.  Bit-identical to cft_focus_s2d(_u8) followed by cft_conv2d.
  */
-int cft_focus_conv(const void* in, int in_u8, long stride_b, long stride_c, long stride_h, float scale,
+int cft_focus_conv(const void* in, int in_kind, long stride_b, long stride_c, long stride_h, float scale,
                    const void* w, int kpad, const float* bias, void* y, int ldy, int yoff,
-                   int B, int H, int W, int n, int act, void* stream);
+                   int B, int H, int W, int n, int act, int dtype, void* stream);
 
 /*
  * SPP max pools (models/common.py:161-165): reads channels [0,C) of the NHWC buffer `buf`
@@ -120,6 +122,14 @@ int cft_spp_maxpool(void* buf, int B, int H, int W, int C, int ld, int k1, int k
  */
 int cft_copy_channels(const void* in, int ldi, int ioff, void* out, int ldo, int ooff,
                       int B, int Ho, int Wo, int C, int up, int dtype, void* stream);
+
+/*
+ * Layout / dtype conversion at the boundary: any strided [B,C,H,W] tensor (in_dtype, element strides) -> NHWC
+ * channel slice [ooff, ooff + pad(C)) of `out` in `dtype`, padding channels zero.  This is what lets a module of
+ * models/common.py be called with an ordinary NCHW torch tensor (as the reference's modules are) without ATen.
+ */
+int cft_to_nhwc(const void* in, int in_dtype, long stride_b, long stride_c, long stride_h, long stride_w,
+                void* out, int ldo, int ooff, int B, int C, int H, int W, int dtype, void* stream);
 
 /* Elementwise out = a + b over M pixels x C channels (Add / Add2, models/common.py:228-243). */
 int cft_add(const void* a, int lda, int aoff, const void* b, int ldb, int boff,

@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libcft_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ("runtime.hip", "conv_gemm.hip", "focus_conv.hip", "bottleneck.hip", "pointwise.hip", "attention.hip", "nms.hip")
 
-CFT_BF16, CFT_F32 = 0, 1
+CFT_BF16, CFT_F32, CFT_F16 = 0, 1, 2
+ABI_VERSION = 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 
 _c = ctypes
@@ -29,10 +30,11 @@ SIGNATURES = {
     "cft_device_check": [],
     "cft_conv2d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_set_conv_variant": [_i],
-    "cft_bottleneck": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_bottleneck": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_focus_s2d": [_vp, _vp, _i, _i, _i, _i, _vp],
     "cft_focus_s2d_u8": [_vp, _l, _l, _l, _vp, _i, _i, _i, _f, _i, _vp],
-    "cft_focus_conv": [_vp, _i, _l, _l, _l, _f, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_focus_conv": [_vp, _i, _l, _l, _l, _f, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_to_nhwc": [_vp, _i, _l, _l, _l, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_spp_maxpool": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_copy_channels": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_add": [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _l, _i, _i, _vp],

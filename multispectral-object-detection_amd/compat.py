@@ -34,15 +34,46 @@ def install_reference_aliases(force=False):
     return pkg
 
 
+def _ensemble_class():
+    import torch
+    import torch.nn as nn
+
+    class Ensemble(nn.ModuleList):
+        """Ensemble of two-stream models (reference models/experimental.py:98-110): every member sees the same
+        pair, the prediction tensors are concatenated along the box axis ("nms ensemble", :108) and the caller's
+        NMS merges them.  (The reference's own ``Ensemble.forward(x, augment)`` passes ONE image to members that
+        need two - it predates the two-stream ``Model.forward(x, x2)``, models/yolo_test.py:214; the pair form is
+        what a two-stream caller needs.)"""
+
+        def forward(self, x, x2, augment=False):
+            y = [module(x, x2, augment)[0] for module in self]
+            return torch.cat(y, 1), None        # members' pred tensors are fresh fp32 [B, rows, no] buffers
+
+    return Ensemble
+
+
 def attempt_load(weights, map_location=None):
-    """Single-checkpoint form of the reference's ``attempt_load`` (models/experimental.py:113-134):
-    load a pickled checkpoint, take ``ema`` or ``model``, ``.float().fuse().eval()``."""
+    """The reference's ``attempt_load`` (models/experimental.py:113-134): ``weights`` is one checkpoint path or a
+    list of them; each pickled checkpoint -> ``ema`` or ``model`` -> ``.float().fuse().eval()`` (an fp32 model,
+    as in the reference: callers then opt into 16-bit with ``model.half()``, test.py:66-68, or with
+    ``set_compute_dtype``).  One path returns the model, several return an ``Ensemble`` carrying the last
+    member's ``names`` / ``stride`` (:129-133)."""
     import torch
     install_reference_aliases()
-    ckpt = torch.load(weights, map_location=map_location, weights_only=False)
-    model = ckpt["ema" if ckpt.get("ema") else "model"] if isinstance(ckpt, dict) else ckpt
-    adopt_torch_modules(model)
-    return model.float().fuse().eval()
+    members = []
+    for w in weights if isinstance(weights, (list, tuple)) else [weights]:
+        ckpt = torch.load(w, map_location=map_location, weights_only=False)
+        model = ckpt["ema" if ckpt.get("ema") else "model"] if isinstance(ckpt, dict) else ckpt
+        adopt_torch_modules(model)
+        members.append(model.float().fuse().eval())
+    if len(members) == 1:
+        return members[-1]
+    ens = _ensemble_class()()
+    for m in members:
+        ens.append(m)
+    for k in ("names", "stride"):
+        setattr(ens, k, getattr(members[-1], k))
+    return ens
 
 
 def adopt_torch_modules(model):

@@ -111,8 +111,9 @@ __global__ void __launch_bounds__(256) attention_kernel(const unsigned char* __r
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       if constexpr (ES == 2) {
-        pf[i][c] = gran_t{pack_bf16x2(s[i][2 * c][0], s[i][2 * c][1]), pack_bf16x2(s[i][2 * c][2], s[i][2 * c][3]),
-                          pack_bf16x2(s[i][2 * c + 1][0], s[i][2 * c + 1][1]), pack_bf16x2(s[i][2 * c + 1][2], s[i][2 * c + 1][3])};
+        typedef Elem<typename Half16<T>::type> E16;
+        pf[i][c] = gran_t{E16::pack2(s[i][2 * c][0], s[i][2 * c][1]), E16::pack2(s[i][2 * c][2], s[i][2 * c][3]),
+                          E16::pack2(s[i][2 * c + 1][0], s[i][2 * c + 1][1]), E16::pack2(s[i][2 * c + 1][2], s[i][2 * c + 1][3])};
       } else {
         pf[i][c] = gran_t{__float_as_uint(s[i][c][0]), __float_as_uint(s[i][c][1]), __float_as_uint(s[i][c][2]), __float_as_uint(s[i][c][3])};
       }
@@ -163,7 +164,10 @@ __global__ void __launch_bounds__(256) attention_kernel(const unsigned char* __r
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = o[i][j][e] * inv_sum[i];
           unsigned char* dst = out + ((long)b * T_TOK + row) * ldo_b + ((long)head * dkp + c0 + j * 16 + lgrp * 4) * ES;
-          if constexpr (ES == 2) *reinterpret_cast<uint2*>(dst) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          if constexpr (ES == 2) {
+            typedef Elem<typename Half16<T>::type> E16;
+            *reinterpret_cast<uint2*>(dst) = uint2{E16::pack2(v[0], v[1]), E16::pack2(v[2], v[3])};
+          }
           else *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{v[0], v[1], v[2], v[3]};
         }
       }
@@ -174,22 +178,17 @@ __global__ void __launch_bounds__(256) attention_kernel(const unsigned char* __r
 extern "C" int cft_attention(const void* qkv, void* out, int B, int heads, int dk, int dkp,
                              int dtype, void* stream) {
   CFT_REQUIRE(qkv && out, "cft_attention: null pointer");
-  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_attention: bad dtype");
-  const int es = dtype == CFT_BF16 ? 2 : 4;
-  const int kstep = dtype == CFT_BF16 ? 32 : 16;
-  CFT_REQUIRE(B > 0 && heads > 0 && dk > 0 && dkp >= dk && dkp % kstep == 0 && dkp <= 256, "cft_attention: dkp must be a multiple of 32 (bf16) / 16 (f32), >= dk, <= 256");
+  CFT_REQUIRE(cft_is_dtype(dtype), "cft_attention: bad dtype");
+  const int es = cft_elem_size(dtype);
+  const int kstep = es == 2 ? 32 : 16;
+  CFT_REQUIRE(B > 0 && heads > 0 && dk > 0 && dkp >= dk && dkp % kstep == 0 && dkp <= 256, "cft_attention: dkp must be a multiple of 32 (bf16, f16) / 16 (f32), >= dk, <= 256");
   const int ps = 128 * es + 16, ks = dkp * es + 16;
   const size_t smem = (size_t)128 * ks + (size_t)64 * ps;
   CFT_REQUIRE(smem <= 160 * 1024, "cft_attention: head too wide for LDS");
   const float scale = 1.0f / sqrtf((float)dk);
-  if (dtype == CFT_BF16) {
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-    hipLaunchKernelGGL(attention_kernel<uint16_t>, dim3(B * heads), dim3(256), smem, as_stream(stream), (const unsigned char*)qkv, (unsigned char*)out, heads, dkp, scale);
-  } else {
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-    hipLaunchKernelGGL(attention_kernel<float>, dim3(B * heads), dim3(256), smem, as_stream(stream), (const unsigned char*)qkv, (unsigned char*)out, heads, dkp, scale);
-  }
+  CFT_DISPATCH_DTYPE(dtype, T, {
+    cft_allow_lds<&attention_kernel<T>>(160 * 1024);
+    hipLaunchKernelGGL(attention_kernel<T>, dim3(B * heads), dim3(256), smem, as_stream(stream), (const unsigned char*)qkv, (unsigned char*)out, heads, dkp, scale);
+  });
   return cft_check_launch("attention_kernel");
 }

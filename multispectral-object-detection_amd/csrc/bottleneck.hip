@@ -29,7 +29,7 @@ struct BneckParams {
 };
 
 // ABL (timing probes only, results wrong): 1 = no phase-1 MFMAs/SiLU (zeros), 2 = no phase-2 MFMAs, 4 = no epilogue
-template <int NT, int ABL = 0>
+template <typename T, int NT, int ABL = 0>   // T: uint16_t (bf16) or f16_t
 __global__ void __launch_bounds__(512) bottleneck_kernel(const BneckParams p) {
   static_assert(NT == 4, "the LDS layout below is for 64 channels (128-byte pixel rows)");
   constexpr int C = NT * 16, TW = 32, TH = 8, PW = TW + 2, PH = TH + 2;
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(512) bottleneck_kernel(const BneckParams p) {
           acc1[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
-            if constexpr (!(ABL & 1)) acc1[j] = mma_granule<uint16_t>(w1f[j][ks], a1[it][ks], acc1[j]);
+            if constexpr (!(ABL & 1)) acc1[j] = mma_granule<T>(w1f[j][ks], a1[it][ks], acc1[j]);
         }
         // this lane's pixel: patch row q (the pixel whose operands it fetched); outside the image t = +0
         const int q = rt * 16 + lrow;
@@ -123,8 +123,8 @@ __global__ void __launch_bounds__(512) bottleneck_kernel(const BneckParams p) {
           for (int e = 0; e < 4; ++e) v[e] = (ABL & 1) ? 0.0f : apply_act<CFT_ACT_SILU>(acc1[j][e] + b1v[j][e]);
           const int n0 = j * 16 + lgrp * 4;   // first of this lane's 4 channels
           uint2 w;
-          w.x = pack_bf16x2(v[0], v[1]) & keep;
-          w.y = pack_bf16x2(v[2], v[3]) & keep;
+          w.x = Elem<T>::pack2(v[0], v[1]) & keep;
+          w.y = Elem<T>::pack2(v[2], v[3]) & keep;
           *reinterpret_cast<uint2*>(sT + q * 128 + ((((n0 >> 3) ^ (q & 7)) << 4) | ((n0 & 7) << 1))) = w;
         }
       }
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(512) bottleneck_kernel(const BneckParams p) {
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             if constexpr (ABL & 2) { asm volatile("" ::"v"(af[i]), "v"(bf[j])); }
-            else acc[i][j] = mma_granule<uint16_t>(af[i], bf[j], acc[i][j]);
+            else acc[i][j] = mma_granule<T>(af[i], bf[j], acc[i][j]);
           }
       }
     }
@@ -211,11 +211,11 @@ __global__ void __launch_bounds__(512) bottleneck_kernel(const BneckParams p) {
           float o[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
           if (p.shortcut) {
             float rf[8];
-            Elem<uint16_t>::unpack(rs[i][v], rf);
+            Elem<T>::unpack(rs[i][v], rf);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] += rf[e];
           }
-          *reinterpret_cast<gran_t*>(p.y + ((img_pix + (long)y * p.W + x) * p.ldy + p.yoff + col) * 2) = Elem<uint16_t>::pack(o);
+          *reinterpret_cast<gran_t*>(p.y + ((img_pix + (long)y * p.W + x) * p.ldy + p.yoff + col) * 2) = Elem<T>::pack(o);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -229,8 +229,9 @@ __global__ void __launch_bounds__(512) bottleneck_kernel(const BneckParams p) {
 
 extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, int kpad1, const float* b1,
                               const void* w2, int kpad2, const float* b2, void* y, int ldy, int yoff,
-                              int B, int H, int W, int c, int shortcut, void* stream) {
+                              int B, int H, int W, int c, int shortcut, int dtype, void* stream) {
   CFT_REQUIRE(x && w1 && w2 && y, "cft_bottleneck: null pointer");
+  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F16, "cft_bottleneck: dtype must be CFT_BF16 or CFT_F16");
   CFT_REQUIRE(c == 64, "cft_bottleneck: the fused kernel covers 64 channels (use two cft_conv2d calls otherwise)");
   CFT_REQUIRE(B > 0 && H > 0 && W > 0, "cft_bottleneck: non-positive size");
   CFT_REQUIRE(kpad1 >= c && kpad1 % 64 == 0 && kpad2 >= 9 * c && kpad2 % 64 == 0, "cft_bottleneck: weights must be packed as for cft_conv2d");
@@ -252,23 +253,24 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
   p.ldx = ldx; p.xoff = xoff; p.ldy = ldy; p.yoff = yoff; p.kpad1 = kpad1; p.kpad2 = kpad2;
   p.H = H; p.W = W; p.tiles_x = (W + 31) / 32; p.bands = (H + 7) / 8; p.shortcut = shortcut ? 1 : 0;
   constexpr int smem_bytes = 9 * 64 * 128 + 22 * 16 * 128;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<4, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    attr_done = true;
-  }
   const dim3 grid(B * p.bands), block(512);
   hipStream_t s = as_stream(stream);
-  switch (g_conv_variant) {   // timing probes (tools/bneck_bench.py)
-    case 901: hipLaunchKernelGGL((bottleneck_kernel<4, 1>), grid, block, smem_bytes, s, p); break;
-    case 902: hipLaunchKernelGGL((bottleneck_kernel<4, 2>), grid, block, smem_bytes, s, p); break;
-    case 904: hipLaunchKernelGGL((bottleneck_kernel<4, 4>), grid, block, smem_bytes, s, p); break;
-    case 907: hipLaunchKernelGGL((bottleneck_kernel<4, 7>), grid, block, smem_bytes, s, p); break;
-    default: hipLaunchKernelGGL((bottleneck_kernel<4>), grid, block, smem_bytes, s, p); break;
+#define BNECK_LAUNCH(T_, ABL_)                                                             \
+  {                                                                                        \
+    cft_allow_lds<&bottleneck_kernel<T_, 4, ABL_>>(smem_bytes);                            \
+    hipLaunchKernelGGL((bottleneck_kernel<T_, 4, ABL_>), grid, block, smem_bytes, s, p);   \
   }
+  if (dtype == CFT_F16) {
+    BNECK_LAUNCH(f16_t, 0)
+  } else {
+    switch (g_conv_variant) {   // timing probes (tools/bneck_bench.py)
+      case 901: BNECK_LAUNCH(uint16_t, 1) break;
+      case 902: BNECK_LAUNCH(uint16_t, 2) break;
+      case 904: BNECK_LAUNCH(uint16_t, 4) break;
+      case 907: BNECK_LAUNCH(uint16_t, 7) break;
+      default: BNECK_LAUNCH(uint16_t, 0) break;
+    }
+  }
+#undef BNECK_LAUNCH
   return cft_check_launch("bottleneck_kernel");
 }

@@ -6,6 +6,10 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+// Element type tags of the kernel templates: uint16_t = bfloat16 bits, f16_t = IEEE half, float.
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 
 // One 16-byte granule: 8 bf16 or 4 f32.  All NHWC tensors are addressed in granules.
 typedef __attribute__((ext_vector_type(4))) uint32_t gran_t;
@@ -24,21 +28,50 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
-// Element traits: T = uint16_t (bf16 bits) or float.
+// two floats -> packed half pair, round-to-nearest-even (v_cvt_f16_f32 x2 + v_pack_b32_f16)
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));
+}
+
+// Element traits: T = uint16_t (bf16 bits), f16_t (IEEE half) or float.
 template <typename T> struct Elem;
 template <> struct Elem<uint16_t> {
   static constexpr int GE = 8;   // elements per 16-byte granule
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+  static __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); }
   static __device__ __forceinline__ void unpack(const gran_t& g, float* f) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(g[i] << 16); f[2 * i + 1] = __uint_as_float(g[i] & 0xffff0000u); }
+    for (int i = 0; i < 4; ++i) unpack2(g[i], f[2 * i], f[2 * i + 1]);
   }
   static __device__ __forceinline__ gran_t pack(const float* f) {
     gran_t g;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) g[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    for (int i = 0; i < 4; ++i) g[i] = pack2(f[2 * i], f[2 * i + 1]);
     return g;
   }
 };
+template <> struct Elem<f16_t> {
+  static constexpr int GE = 8;
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
+  static __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) {
+    const f32x2_t v = __builtin_convertvector(__builtin_bit_cast(f16x2_t, w), f32x2_t);
+    lo = v[0]; hi = v[1];
+  }
+  static __device__ __forceinline__ void unpack(const gran_t& g, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) unpack2(g[i], f[2 * i], f[2 * i + 1]);
+  }
+  static __device__ __forceinline__ gran_t pack(const float* f) {
+    gran_t g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[i] = pack2(f[2 * i], f[2 * i + 1]);
+    return g;
+  }
+};
+// 16-bit storage type that goes with compute type T (T itself when it is 16 bits wide; bf16 for the
+// never-launched 16-bit-output instantiations of the fp32 kernels).
+template <typename T> struct Half16 { typedef T type; };
+template <> struct Half16<float> { typedef uint16_t type; };
 template <> struct Elem<float> {
   static constexpr int GE = 4;
   static __device__ __forceinline__ void unpack(const gran_t& g, float* f) {
@@ -62,6 +95,10 @@ __device__ __forceinline__ f32x4_t mma_granule(const gran_t& a, const gran_t& b,
 template <>
 __device__ __forceinline__ f32x4_t mma_granule<uint16_t>(const gran_t& a, const gran_t& b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t mma_granule<f16_t>(const gran_t& a, const gran_t& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 template <>
 __device__ __forceinline__ f32x4_t mma_granule<float>(const gran_t& a, const gran_t& b, f32x4_t c) {
@@ -90,6 +127,34 @@ __device__ __forceinline__ float apply_act(float v) {
 void cft_set_error(const char* msg);
 int cft_check_launch(const char* what);
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+// Dynamic-LDS opt-in of one kernel, once per (kernel, device): the attribute is per device, so a process that
+// drives several GPUs must set it on each.
+template <auto Kernel>
+static inline void cft_allow_lds(int bytes) {
+  static bool done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return;
+  }
+  if (!done[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done[dev] = true;
+  }
+}
+
+static inline bool cft_is_dtype(int d) { return d == CFT_BF16 || d == CFT_F16 || d == CFT_F32; }
+static inline int cft_elem_size(int d) { return d == CFT_F32 ? 4 : 2; }
+static inline int cft_granule(int d) { return d == CFT_F32 ? 4 : 8; }
+
+// Run `...` with `T` bound to the element tag of dtype code `dt_`.
+#define CFT_DISPATCH_DTYPE(dt_, T, ...)                              \
+  do {                                                               \
+    if ((dt_) == CFT_BF16) { using T = uint16_t; __VA_ARGS__; }      \
+    else if ((dt_) == CFT_F16) { using T = f16_t; __VA_ARGS__; }     \
+    else { using T = float; __VA_ARGS__; }                           \
+  } while (0)
 
 #define CFT_REQUIRE(cond, msg)            \
   do {                                    \

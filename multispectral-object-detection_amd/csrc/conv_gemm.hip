@@ -60,7 +60,7 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // acc (+bias, activation) -> 16-row fp32 LDS strip -> rows re-read as 16-B vectors -> (+residual)
 // -> one rounding -> coalesced 16-B stores.  The caller guarantees (barrier) that no wave still
 // reads the staging buffers that the strips alias.
-template <int WM, int WN, int ACT, bool OUT_F32>
+template <typename TH, int WM, int WN, int ACT, bool OUT_F32>   // TH: the 16-bit storage type (bf16 bits or half)
 __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4_t (&acc)[WM / 16][WN / 16], unsigned char* smem,
                                                    int m0, int n0, int wm, int wn, int wave, int lane) {
   constexpr int MT = WM / 16, NT = WN / 16;
@@ -124,8 +124,10 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4_t 
               v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
             } else {
               const uint2 rr = *reinterpret_cast<const uint2*>(p.res + ro * 2);
-              v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-              v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+              float r0, r1, r2, r3;
+              Elem<TH>::unpack2(rr.x, r0, r1);
+              Elem<TH>::unpack2(rr.y, r2, r3);
+              v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
             }
           }
           *reinterpret_cast<f32x4_t*>(p.y + ((long)m * p.ldy + p.yoff + n) * 4) = f32x4_t{v[0], v[1], v[2], v[3]};
@@ -144,7 +146,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4_t 
           float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
           if (res_pre) {
             float rf[8];
-            Elem<uint16_t>::unpack(rpre[i % RDEPTH][vi], rf);
+            Elem<TH>::unpack(rpre[i % RDEPTH][vi], rf);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += rf[e];
           } else if (p.res != nullptr) {   // fp32 residual stream of the CFT block
@@ -154,7 +156,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4_t 
             v[0] += r0v.x; v[1] += r0v.y; v[2] += r0v.z; v[3] += r0v.w;
             v[4] += r1v.x; v[5] += r1v.y; v[6] += r1v.z; v[7] += r1v.w;
           }
-          *reinterpret_cast<gran_t*>(p.y + ((long)m * p.ldy + p.yoff + n) * 2) = Elem<uint16_t>::pack(v);
+          *reinterpret_cast<gran_t*>(p.y + ((long)m * p.ldy + p.yoff + n) * 2) = Elem<TH>::pack(v);
         }
       }
       if (res_pre && i + RDEPTH < MT) CFT_RES_FETCH(i + RDEPTH)
@@ -168,17 +170,17 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4_t 
 #undef CFT_RES_FETCH
 
 // Uniform dispatch to the specialised epilogues (one activation / output type per launch).
-template <int WM, int WN>
+template <typename TH, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc)[WM / 16][WN / 16], unsigned char* smem,
                                               int m0, int n0, int wm, int wn, int wave, int lane) {
   if (p.out_f32) {
-    if (p.act == CFT_ACT_SILU) conv_epilogue_impl<WM, WN, CFT_ACT_SILU, true>(p, acc, smem, m0, n0, wm, wn, wave, lane);
-    else if (p.act == CFT_ACT_GELU) conv_epilogue_impl<WM, WN, CFT_ACT_GELU, true>(p, acc, smem, m0, n0, wm, wn, wave, lane);
-    else conv_epilogue_impl<WM, WN, CFT_ACT_NONE, true>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+    if (p.act == CFT_ACT_SILU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_SILU, true>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+    else if (p.act == CFT_ACT_GELU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_GELU, true>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+    else conv_epilogue_impl<TH, WM, WN, CFT_ACT_NONE, true>(p, acc, smem, m0, n0, wm, wn, wave, lane);
   } else {
-    if (p.act == CFT_ACT_SILU) conv_epilogue_impl<WM, WN, CFT_ACT_SILU, false>(p, acc, smem, m0, n0, wm, wn, wave, lane);
-    else if (p.act == CFT_ACT_GELU) conv_epilogue_impl<WM, WN, CFT_ACT_GELU, false>(p, acc, smem, m0, n0, wm, wn, wave, lane);
-    else conv_epilogue_impl<WM, WN, CFT_ACT_NONE, false>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+    if (p.act == CFT_ACT_SILU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_SILU, false>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+    else if (p.act == CFT_ACT_GELU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_GELU, false>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+    else conv_epilogue_impl<TH, WM, WN, CFT_ACT_NONE, false>(p, acc, smem, m0, n0, wm, wn, wave, lane);
   }
 }
 
@@ -351,7 +353,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
       for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  conv_epilogue<WM, WN>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+  conv_epilogue<typename Half16<T>::type, WM, WN>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------ host
@@ -376,12 +378,7 @@ extern "C" int cft_set_conv_variant(int v) {
 template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
   constexpr int smem_bytes = 2 * (BM + BN) * 128;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    attr_done = true;
-  }
+  cft_allow_lds<&conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE>>(smem_bytes);
   ConvParams q = p;
   const int tilesM = (p.M + BM - 1) / BM;
   q.tilesN = (p.N + BN - 1) / BN;
@@ -463,12 +460,12 @@ extern "C" int cft_conv2d(const void* x, const void* w, const float* bias, const
                           int ldy, int yoff, int ldr, int roff,
                           int act, int dtype, int out_dtype, int res_dtype, void* stream) {
   CFT_REQUIRE(x && w && y, "cft_conv2d: null pointer");
-  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_conv2d: dtype must be CFT_BF16 or CFT_F32");
-  CFT_REQUIRE(out_dtype == CFT_BF16 || out_dtype == CFT_F32, "cft_conv2d: bad out_dtype");
-  CFT_REQUIRE(!(dtype == CFT_F32 && out_dtype == CFT_BF16), "cft_conv2d: f32 compute writes f32");
+  CFT_REQUIRE(cft_is_dtype(dtype), "cft_conv2d: dtype must be CFT_BF16, CFT_F16 or CFT_F32");
+  CFT_REQUIRE(out_dtype == dtype || out_dtype == CFT_F32, "cft_conv2d: out_dtype must be the compute dtype or CFT_F32");
+  CFT_REQUIRE(res == nullptr || res_dtype == dtype || res_dtype == CFT_F32, "cft_conv2d: res_dtype must be the compute dtype or CFT_F32");
   CFT_REQUIRE(B > 0 && H > 0 && W > 0 && cin > 0 && n > 0, "cft_conv2d: non-positive size");
   CFT_REQUIRE(ksize >= 1 && ksize <= 5 && (ksize & 1) && stride >= 1, "cft_conv2d: ksize must be 1, 3 or 5");
-  const int ge = dtype == CFT_BF16 ? 8 : 4, bk = 8 * ge;
+  const int ge = cft_granule(dtype), bk = 8 * ge;
   CFT_REQUIRE(cin % ge == 0 && ldx % ge == 0 && xoff % ge == 0, "cft_conv2d: input channels/ld/offset not granule aligned");
   CFT_REQUIRE(kpad % bk == 0 && kpad >= ksize * ksize * cin, "cft_conv2d: kpad must cover k*k*cin and be a multiple of the K step");
   CFT_REQUIRE(n % 8 == 0 && ldy % 8 == 0 && yoff % 8 == 0, "cft_conv2d: n/ldy/yoff must be multiples of 8");
@@ -489,5 +486,6 @@ extern "C" int cft_conv2d(const void* x, const void* w, const float* bias, const
   p.M = (int)M; p.tilesN = 0;
   set_magic(Wo, p.wo_mul, p.wo_sh);
   set_magic(Ho, p.ho_mul, p.ho_sh);
-  return dtype == CFT_BF16 ? dispatch_conv<uint16_t>(p, as_stream(stream)) : dispatch_conv<float>(p, as_stream(stream));
+  CFT_DISPATCH_DTYPE(dtype, T, return dispatch_conv<T>(p, as_stream(stream)));
+  return CFT_EINVAL;
 }

@@ -36,13 +36,19 @@ __device__ __forceinline__ void load_pair<float>(const float* p, float scale, fl
   b = t.y * scale;
 }
 template <>
+__device__ __forceinline__ void load_pair<f16_t>(const f16_t* p, float scale, float& a, float& b) {   // half images (`img.half()`, test.py:107)
+  const f32x2_t t = __builtin_convertvector(*reinterpret_cast<const f16x2_t*>(p), f32x2_t);
+  a = t[0] * scale;
+  b = t[1] * scale;
+}
+template <>
 __device__ __forceinline__ void load_pair<unsigned char>(const unsigned char* p, float scale, float& a, float& b) {
   const unsigned short t = *reinterpret_cast<const unsigned short*>(p);
   a = (float)(t & 0xffu) * scale;
   b = (float)(t >> 8) * scale;
 }
 
-template <typename IN, int NT, int ACT>
+template <typename T, typename IN, int NT, int ACT>   // T: uint16_t (bf16) or f16_t compute/output; IN: image element
 __global__ void __launch_bounds__(512) focus_conv_kernel(const FocusConvParams p) {
   constexpr int N = NT * 16, TW = 64, TH = 4, PW = TW + 2, PH = TH + 2;
   constexpr int W_BYTES = 3 * N * 128;        // three 64-wide K steps of the [N][192] weight, 128-B rows
@@ -104,8 +110,8 @@ __global__ void __launch_bounds__(512) focus_conv_kernel(const FocusConvParams p
       for (int e = 0; e < 12; ++e) v[e] = raw[e];
       v[12] = v[13] = v[14] = v[15] = 0.0f;
       gran_t* o = reinterpret_cast<gran_t*>(sZ + tid * 32);
-      o[0] = Elem<uint16_t>::pack(v);
-      o[1] = Elem<uint16_t>::pack(v + 8);
+      o[0] = Elem<T>::pack(v);
+      o[1] = Elem<T>::pack(v + 8);
     }
     if (tid == PH * PW) *reinterpret_cast<gran_t*>(sZ + ZERO_OFF) = gran_t{0u, 0u, 0u, 0u};
     lds_barrier();
@@ -135,7 +141,7 @@ __global__ void __launch_bounds__(512) focus_conv_kernel(const FocusConvParams p
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = mma_granule<uint16_t>(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < NT; ++j) acc[i][j] = mma_granule<T>(af[i], bf[j], acc[i][j]);
     }
     lds_barrier();   // every wave is done with the patch before the strips overwrite it
 
@@ -158,7 +164,7 @@ __global__ void __launch_bounds__(512) focus_conv_kernel(const FocusConvParams p
           const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col + 4);
           const float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
           const long m = ((long)b * p.Ho + y) * p.Wo + x;
-          *reinterpret_cast<gran_t*>(p.y + (m * p.ldy + p.yoff + col) * 2) = Elem<uint16_t>::pack(v);
+          *reinterpret_cast<gran_t*>(p.y + (m * p.ldy + p.yoff + col) * 2) = Elem<T>::pack(v);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -170,42 +176,52 @@ __global__ void __launch_bounds__(512) focus_conv_kernel(const FocusConvParams p
 #undef FOCUS_FETCH
 }
 
-template <typename IN, int NT, int ACT>
+template <typename T, typename IN, int NT, int ACT>
 static int launch_focus_conv(const FocusConvParams& p, int B, hipStream_t stream) {
   constexpr int N = NT * 16;
   constexpr int patch = 6 * 66 * 32 + 16, strips = 8 * 16 * (N + 4) * 4;
   constexpr int smem_bytes = 3 * N * 128 + (patch > strips ? patch : strips);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&focus_conv_kernel<IN, NT, ACT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((focus_conv_kernel<IN, NT, ACT>), dim3(B * p.bands), dim3(512), smem_bytes, stream, p);
+  cft_allow_lds<&focus_conv_kernel<T, IN, NT, ACT>>(smem_bytes);
+  hipLaunchKernelGGL((focus_conv_kernel<T, IN, NT, ACT>), dim3(B * p.bands), dim3(512), smem_bytes, stream, p);
   return cft_check_launch("focus_conv_kernel");
 }
 
-template <typename IN, int ACT>
+template <typename T, typename IN, int ACT>
 static int dispatch_focus_conv(const FocusConvParams& p, int B, int n, hipStream_t stream) {
   switch (n) {
-    case 32: return launch_focus_conv<IN, 2, ACT>(p, B, stream);
-    case 48: return launch_focus_conv<IN, 3, ACT>(p, B, stream);
-    case 64: return launch_focus_conv<IN, 4, ACT>(p, B, stream);
-    default: return launch_focus_conv<IN, 5, ACT>(p, B, stream);
+    case 32: return launch_focus_conv<T, IN, 2, ACT>(p, B, stream);
+    case 48: return launch_focus_conv<T, IN, 3, ACT>(p, B, stream);
+    case 64: return launch_focus_conv<T, IN, 4, ACT>(p, B, stream);
+    default: return launch_focus_conv<T, IN, 5, ACT>(p, B, stream);
   }
 }
+template <typename T, typename IN>
+static int dispatch_focus_act(const FocusConvParams& p, int B, int n, int act, hipStream_t stream) {
+  return act == CFT_ACT_SILU ? dispatch_focus_conv<T, IN, CFT_ACT_SILU>(p, B, n, stream) : dispatch_focus_conv<T, IN, CFT_ACT_NONE>(p, B, n, stream);
+}
+template <typename T>
+static int dispatch_focus_in(const FocusConvParams& p, int B, int n, int act, int in_kind, hipStream_t stream) {
+  if (in_kind == 1) return dispatch_focus_act<T, unsigned char>(p, B, n, act, stream);
+  if constexpr (sizeof(T) == 2 && !__is_same(T, uint16_t)) {   // half images go with half compute (`model.half()` + `img.half()`)
+    if (in_kind == 2) return dispatch_focus_act<T, f16_t>(p, B, n, act, stream);
+  }
+  return dispatch_focus_act<T, float>(p, B, n, act, stream);
+}
 
-extern "C" int cft_focus_conv(const void* in, int in_u8, long stride_b, long stride_c, long stride_h, float scale,
+extern "C" int cft_focus_conv(const void* in, int in_kind, long stride_b, long stride_c, long stride_h, float scale,
                               const void* w, int kpad, const float* bias, void* y, int ldy, int yoff,
-                              int B, int H, int W, int n, int act, void* stream) {
+                              int B, int H, int W, int n, int act, int dtype, void* stream) {
   CFT_REQUIRE(in && w && y, "cft_focus_conv: null pointer");
+  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F16, "cft_focus_conv: dtype must be CFT_BF16 or CFT_F16");
+  CFT_REQUIRE(in_kind >= 0 && in_kind <= 2, "cft_focus_conv: in_kind must be 0 (float), 1 (uint8) or 2 (half)");
+  CFT_REQUIRE(in_kind != 2 || dtype == CFT_F16, "cft_focus_conv: half images require dtype CFT_F16");
   CFT_REQUIRE(B > 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0), "cft_focus_conv: H and W must be even");
   CFT_REQUIRE(n == 32 || n == 48 || n == 64 || n == 80, "cft_focus_conv: n must be 32, 48, 64 or 80 (use cft_focus_s2d + cft_conv2d otherwise)");
   CFT_REQUIRE(kpad == 192, "cft_focus_conv: weights must be packed as [n][192] (3x3 taps x 16 channels, zero padded)");
   CFT_REQUIRE(act == CFT_ACT_SILU || act == CFT_ACT_NONE, "cft_focus_conv: activation must be SiLU or none");
   CFT_REQUIRE(ldy % 8 == 0 && yoff % 8 == 0 && ldy >= yoff + n, "cft_focus_conv: bad output ld/offset");
   CFT_REQUIRE(stride_h >= W && stride_c > 0 && stride_b > 0, "cft_focus_conv: bad strides");
-  const long es = in_u8 ? 1 : 4;
+  const long es = in_kind == 1 ? 1 : (in_kind == 2 ? 2 : 4);
   CFT_REQUIRE(((long)(size_t)in * 1 % (2 * es) == 0) && stride_h % 2 == 0 && stride_c % 2 == 0 && stride_b % 2 == 0,
               "cft_focus_conv: image rows must start on pixel-pair boundaries (pointer and strides even)");
   FocusConvParams p;
@@ -215,8 +231,5 @@ extern "C" int cft_focus_conv(const void* in, int in_u8, long stride_b, long str
   p.Ho = H / 2; p.Wo = W / 2; p.tiles_x = (p.Wo + 63) / 64; p.bands = (p.Ho + 3) / 4;
   CFT_REQUIRE((long)B * p.bands < (1L << 31) && (long)B * p.Ho * p.Wo * ldy < (1L << 40), "cft_focus_conv: tensor too large");
   hipStream_t s = as_stream(stream);
-  if (in_u8) return act == CFT_ACT_SILU ? dispatch_focus_conv<unsigned char, CFT_ACT_SILU>(p, B, n, s)
-                                        : dispatch_focus_conv<unsigned char, CFT_ACT_NONE>(p, B, n, s);
-  return act == CFT_ACT_SILU ? dispatch_focus_conv<float, CFT_ACT_SILU>(p, B, n, s)
-                             : dispatch_focus_conv<float, CFT_ACT_NONE>(p, B, n, s);
+  return dtype == CFT_BF16 ? dispatch_focus_in<uint16_t>(p, B, n, act, in_kind, s) : dispatch_focus_in<f16_t>(p, B, n, act, in_kind, s);
 }

@@ -45,13 +45,10 @@ __global__ void __launch_bounds__(256) focus_s2d_kernel(const float* __restrict_
 extern "C" int cft_focus_s2d(const float* in, void* out, int B, int H, int W, int dtype, void* stream) {
   CFT_REQUIRE(in && out, "cft_focus_s2d: null pointer");
   CFT_REQUIRE(B > 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0), "cft_focus_s2d: H and W must be even");
-  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_focus_s2d: bad dtype");
+  CFT_REQUIRE(cft_is_dtype(dtype), "cft_focus_s2d: bad dtype");
   const long total = (long)B * (H / 2) * (W / 2);
   const int grid = grid_for(total, 256);
-  if (dtype == CFT_BF16)
-    hipLaunchKernelGGL(focus_s2d_kernel<uint16_t>, dim3(grid), dim3(256), 0, as_stream(stream), in, (unsigned char*)out, B, H, W);
-  else
-    hipLaunchKernelGGL(focus_s2d_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), in, (unsigned char*)out, B, H, W);
+  CFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(focus_s2d_kernel<T>, dim3(grid), dim3(256), 0, as_stream(stream), in, (unsigned char*)out, B, H, W));
   return cft_check_launch("focus_s2d_kernel");
 }
 
@@ -90,14 +87,11 @@ extern "C" int cft_focus_s2d_u8(const unsigned char* in, long stride_b, long str
                                 int B, int H, int W, float scale, int dtype, void* stream) {
   CFT_REQUIRE(in && out, "cft_focus_s2d_u8: null pointer");
   CFT_REQUIRE(B > 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0), "cft_focus_s2d_u8: H and W must be even");
-  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_focus_s2d_u8: bad dtype");
+  CFT_REQUIRE(cft_is_dtype(dtype), "cft_focus_s2d_u8: bad dtype");
   CFT_REQUIRE(stride_h >= W && stride_c > 0 && stride_b > 0, "cft_focus_s2d_u8: bad strides");
   const long total = (long)B * (H / 2) * (W / 2);
   const int grid = grid_for(total, 256);
-  if (dtype == CFT_BF16)
-    hipLaunchKernelGGL(focus_s2d_u8_kernel<uint16_t>, dim3(grid), dim3(256), 0, as_stream(stream), in, stride_b, stride_c, stride_h, (unsigned char*)out, B, H, W, scale);
-  else
-    hipLaunchKernelGGL(focus_s2d_u8_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), in, stride_b, stride_c, stride_h, (unsigned char*)out, B, H, W, scale);
+  CFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(focus_s2d_u8_kernel<T>, dim3(grid), dim3(256), 0, as_stream(stream), in, stride_b, stride_c, stride_h, (unsigned char*)out, B, H, W, scale));
   return cft_check_launch("focus_s2d_u8_kernel");
 }
 
@@ -214,8 +208,8 @@ __global__ void __launch_bounds__(512) spp_chain_kernel(unsigned char* buf, int 
 extern "C" int cft_spp_maxpool(void* buf, int B, int H, int W, int C, int ld, int k1, int k2, int k3,
                                int dtype, void* stream) {
   CFT_REQUIRE(buf != nullptr, "cft_spp_maxpool: null pointer");
-  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_spp_maxpool: bad dtype");
-  const int ge = dtype == CFT_BF16 ? 8 : 4;
+  CFT_REQUIRE(cft_is_dtype(dtype), "cft_spp_maxpool: bad dtype");
+  const int ge = cft_granule(dtype);
   CFT_REQUIRE(C % ge == 0 && ld % ge == 0 && ld >= 4 * C, "cft_spp_maxpool: C/ld not granule aligned or ld < 4C");
   CFT_REQUIRE((k1 & 1) && (k2 & 1) && (k3 & 1) && k1 <= k2 && k2 <= k3 && k3 <= 13 && k1 >= 1, "cft_spp_maxpool: kernel sizes must be odd, ascending, <= 13");
   const int r1 = k1 / 2, r2 = k2 / 2, r3 = k3 / 2, gpc = C / ge;
@@ -225,29 +219,19 @@ extern "C" int cft_spp_maxpool(void* buf, int B, int H, int W, int C, int ld, in
       if (gpc % g == 0 && (size_t)2 * H * W * g * 16 <= 64 * 1024) { G = g; break; }
     const size_t smem = (size_t)2 * H * W * G * 16;
     const int grid = B * (gpc / G);
-    if (dtype == CFT_BF16) {
-      static bool done = false;
-      if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spp_chain_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-      hipLaunchKernelGGL(spp_chain_kernel<uint16_t>, dim3(grid), dim3(512), smem, as_stream(stream), (unsigned char*)buf, H, W, C, ld, r1, G);
-    } else {
-      static bool done = false;
-      if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spp_chain_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-      hipLaunchKernelGGL(spp_chain_kernel<float>, dim3(grid), dim3(512), smem, as_stream(stream), (unsigned char*)buf, H, W, C, ld, r1, G);
-    }
+    CFT_DISPATCH_DTYPE(dtype, T, {
+      cft_allow_lds<&spp_chain_kernel<T>>(160 * 1024);
+      hipLaunchKernelGGL(spp_chain_kernel<T>, dim3(grid), dim3(512), smem, as_stream(stream), (unsigned char*)buf, H, W, C, ld, r1, G);
+    });
     return cft_check_launch("spp_chain_kernel");
   }
   const size_t smem = (size_t)4 * H * W * 16;
   CFT_REQUIRE(smem <= 160 * 1024, "cft_spp_maxpool: feature map too large for the LDS plane (H*W <= 2560)");
   const int grid = B * gpc;
-  if (dtype == CFT_BF16) {
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spp_maxpool_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-    hipLaunchKernelGGL(spp_maxpool_kernel<uint16_t>, dim3(grid), dim3(256), smem, as_stream(stream), (unsigned char*)buf, H, W, C, ld, r1, r2, r3);
-  } else {
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spp_maxpool_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-    hipLaunchKernelGGL(spp_maxpool_kernel<float>, dim3(grid), dim3(256), smem, as_stream(stream), (unsigned char*)buf, H, W, C, ld, r1, r2, r3);
-  }
+  CFT_DISPATCH_DTYPE(dtype, T, {
+    cft_allow_lds<&spp_maxpool_kernel<T>>(160 * 1024);
+    hipLaunchKernelGGL(spp_maxpool_kernel<T>, dim3(grid), dim3(256), smem, as_stream(stream), (unsigned char*)buf, H, W, C, ld, r1, r2, r3);
+  });
   return cft_check_launch("spp_maxpool_kernel");
 }
 
@@ -273,8 +257,8 @@ __global__ void __launch_bounds__(256) copy_channels_kernel(const unsigned char*
 extern "C" int cft_copy_channels(const void* in, int ldi, int ioff, void* out, int ldo, int ooff,
                                  int B, int Ho, int Wo, int C, int up, int dtype, void* stream) {
   CFT_REQUIRE(in && out, "cft_copy_channels: null pointer");
-  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_copy_channels: bad dtype");
-  const int ge = dtype == CFT_BF16 ? 8 : 4, es = dtype == CFT_BF16 ? 2 : 4;
+  CFT_REQUIRE(cft_is_dtype(dtype), "cft_copy_channels: bad dtype");
+  const int ge = cft_granule(dtype), es = cft_elem_size(dtype);
   CFT_REQUIRE(C % ge == 0 && ldi % ge == 0 && ioff % ge == 0 && ldo % ge == 0 && ooff % ge == 0, "cft_copy_channels: not granule aligned");
   CFT_REQUIRE(up >= 0 && up <= 3 && (Ho % (1 << up) == 0) && (Wo % (1 << up) == 0), "cft_copy_channels: bad upsample shift");
   const int gpp = C / ge;
@@ -283,6 +267,59 @@ extern "C" int cft_copy_channels(const void* in, int ldi, int ioff, void* out, i
                      (const unsigned char*)in, (long)ldi * es, (long)ioff * es, (unsigned char*)out, (long)ldo * es, (long)ooff * es,
                      B, Ho, Wo, gpp, up);
   return cft_check_launch("copy_channels_kernel");
+}
+
+// ------------------------------------------------------------------------------- layout / dtype conversion
+// Any strided [B,C,H,W] tensor (fp32 / bf16 / half, e.g. a plain NCHW torch tensor handed to one of the modules)
+// -> NHWC channel slice in the compute dtype; channels [C, Cpad) are zero filled.  Boundary helper, not on the
+// hot path: inside the network every producer already writes NHWC.
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) to_nhwc_kernel(const unsigned char* __restrict__ in, long sb, long sc, long sh, long sw,
+                                                      unsigned char* __restrict__ out, long ldo_b, long ooff_b,
+                                                      int B, int C, int H, int W, int gpp) {
+  constexpr int GE = Elem<TO>::GE;
+  const long total = (long)B * H * W * gpp;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int gidx = (int)(idx % gpp);
+    long t = idx / gpp;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    float v[GE];
+#pragma unroll
+    for (int e = 0; e < GE; ++e) {
+      const int c = gidx * GE + e;
+      float f = 0.0f;
+      if (c < C) {
+        const long o = (long)b * sb + (long)c * sc + (long)y * sh + (long)x * sw;
+        if constexpr (sizeof(TI) == 4) f = reinterpret_cast<const float*>(in)[o];
+        else {
+          float lo, hi;
+          Elem<TI>::unpack2((uint32_t)reinterpret_cast<const uint16_t*>(in)[o], lo, hi);
+          f = lo;
+        }
+      }
+      v[e] = f;
+    }
+    *reinterpret_cast<gran_t*>(out + (((long)b * H + y) * W + x) * ldo_b + ooff_b + gidx * 16L) = Elem<TO>::pack(v);
+  }
+}
+
+extern "C" int cft_to_nhwc(const void* in, int in_dtype, long stride_b, long stride_c, long stride_h, long stride_w,
+                           void* out, int ldo, int ooff, int B, int C, int H, int W, int dtype, void* stream) {
+  CFT_REQUIRE(in && out, "cft_to_nhwc: null pointer");
+  CFT_REQUIRE(cft_is_dtype(in_dtype) && cft_is_dtype(dtype), "cft_to_nhwc: bad dtype");
+  CFT_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "cft_to_nhwc: non-positive size");
+  const int ge = cft_granule(dtype), es = cft_elem_size(dtype);
+  CFT_REQUIRE(ldo % ge == 0 && ooff % ge == 0 && ldo >= ooff + C, "cft_to_nhwc: output ld/offset not granule aligned or too small");
+  const int gpp = (C + ge - 1) / ge;
+  CFT_REQUIRE(ooff + gpp * ge <= ldo, "cft_to_nhwc: padded channel count exceeds ld");
+  const long total = (long)B * H * W * gpp;
+  const int grid = grid_for(total, 256);
+  CFT_DISPATCH_DTYPE(in_dtype, TI, CFT_DISPATCH_DTYPE(dtype, TO,
+      hipLaunchKernelGGL((to_nhwc_kernel<TI, TO>), dim3(grid), dim3(256), 0, as_stream(stream), (const unsigned char*)in, stride_b, stride_c, stride_h, stride_w,
+                         (unsigned char*)out, (long)ldo * es, (long)ooff * es, B, C, H, W, gpp)));
+  return cft_check_launch("to_nhwc_kernel");
 }
 
 // ------------------------------------------------------------------------------- add
@@ -307,18 +344,14 @@ __global__ void __launch_bounds__(256) add_kernel(const unsigned char* a, long l
 extern "C" int cft_add(const void* a, int lda, int aoff, const void* b, int ldb, int boff,
                        void* out, int ldo, int ooff, long M, int C, int dtype, void* stream) {
   CFT_REQUIRE(a && b && out, "cft_add: null pointer");
-  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_add: bad dtype");
-  const int ge = dtype == CFT_BF16 ? 8 : 4, es = dtype == CFT_BF16 ? 2 : 4;
+  CFT_REQUIRE(cft_is_dtype(dtype), "cft_add: bad dtype");
+  const int ge = cft_granule(dtype), es = cft_elem_size(dtype);
   CFT_REQUIRE(C % ge == 0 && lda % ge == 0 && aoff % ge == 0 && ldb % ge == 0 && boff % ge == 0 && ldo % ge == 0 && ooff % ge == 0,
               "cft_add: not granule aligned");
   const int gpp = C / ge;
   const int grid = grid_for(M * gpp, 256);
-  if (dtype == CFT_BF16)
-    hipLaunchKernelGGL(add_kernel<uint16_t>, dim3(grid), dim3(256), 0, as_stream(stream), (const unsigned char*)a, (long)lda * es, (long)aoff * es,
-                       (const unsigned char*)b, (long)ldb * es, (long)boff * es, (unsigned char*)out, (long)ldo * es, (long)ooff * es, M, gpp);
-  else
-    hipLaunchKernelGGL(add_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const unsigned char*)a, (long)lda * es, (long)aoff * es,
-                       (const unsigned char*)b, (long)ldb * es, (long)boff * es, (unsigned char*)out, (long)ldo * es, (long)ooff * es, M, gpp);
+  CFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(add_kernel<T>, dim3(grid), dim3(256), 0, as_stream(stream), (const unsigned char*)a, (long)lda * es, (long)aoff * es,
+                                                   (const unsigned char*)b, (long)ldb * es, (long)boff * es, (unsigned char*)out, (long)ldo * es, (long)ooff * es, M, gpp));
   return cft_check_launch("add_kernel");
 }
 
@@ -359,18 +392,14 @@ extern "C" int cft_gpt_tokenize(const void* rgb, int ld_rgb, int off_rgb, const 
                                 const float* pos_emb, float* tokens, int B, int H, int W, int C,
                                 int dtype, void* stream) {
   CFT_REQUIRE(rgb && ir && pos_emb && tokens, "cft_gpt_tokenize: null pointer");
-  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_gpt_tokenize: bad dtype");
-  const int ge = dtype == CFT_BF16 ? 8 : 4, es = dtype == CFT_BF16 ? 2 : 4;
+  CFT_REQUIRE(cft_is_dtype(dtype), "cft_gpt_tokenize: bad dtype");
+  const int ge = cft_granule(dtype), es = cft_elem_size(dtype);
   CFT_REQUIRE(C % ge == 0 && ld_rgb % ge == 0 && off_rgb % ge == 0 && ld_ir % ge == 0 && off_ir % ge == 0, "cft_gpt_tokenize: not granule aligned");
   CFT_REQUIRE(B > 0 && H >= 1 && W >= 1, "cft_gpt_tokenize: bad shape");
   int threads = C / ge;
   threads = threads < 64 ? 64 : (threads > 256 ? 256 : ((threads + 63) / 64) * 64);
-  if (dtype == CFT_BF16)
-    hipLaunchKernelGGL(gpt_tokenize_kernel<uint16_t>, dim3(B * 128), dim3(threads), 0, as_stream(stream), (const unsigned char*)rgb, (long)ld_rgb * es, (long)off_rgb * es,
-                       (const unsigned char*)ir, (long)ld_ir * es, (long)off_ir * es, pos_emb, tokens, H, W, C);
-  else
-    hipLaunchKernelGGL(gpt_tokenize_kernel<float>, dim3(B * 128), dim3(threads), 0, as_stream(stream), (const unsigned char*)rgb, (long)ld_rgb * es, (long)off_rgb * es,
-                       (const unsigned char*)ir, (long)ld_ir * es, (long)off_ir * es, pos_emb, tokens, H, W, C);
+  CFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(gpt_tokenize_kernel<T>, dim3(B * 128), dim3(threads), 0, as_stream(stream), (const unsigned char*)rgb, (long)ld_rgb * es, (long)off_rgb * es,
+                                                   (const unsigned char*)ir, (long)ld_ir * es, (long)off_ir * es, pos_emb, tokens, H, W, C));
   return cft_check_launch("gpt_tokenize_kernel");
 }
 
@@ -379,7 +408,7 @@ extern "C" int cft_gpt_tokenize(const void* rgb, int ld_rgb, int off_rgb, const 
 template <int MAXV>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, unsigned char* __restrict__ y,
-                                                        long rows, int C, float eps, int out_f32) {
+                                                        long rows, int C, float eps, int out_dtype) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -416,12 +445,12 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
       const float4 bt = reinterpret_cast<const float4*>(beta)[idx];
       float o[4] = {(v[k].x - mean) * rstd * gm.x + bt.x, (v[k].y - mean) * rstd * gm.y + bt.y,
                     (v[k].z - mean) * rstd * gm.z + bt.z, (v[k].w - mean) * rstd * gm.w + bt.w};
-      if (out_f32) {
+      if (out_dtype == CFT_F32) {
         *reinterpret_cast<float4*>(y + (row * C + idx * 4L) * 4) = *reinterpret_cast<float4*>(o);
       } else {
         uint2 pk;
-        pk.x = pack_bf16x2(o[0], o[1]);
-        pk.y = pack_bf16x2(o[2], o[3]);
+        if (out_dtype == CFT_BF16) { pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]); }
+        else { pk.x = pack_f16x2(o[0], o[1]); pk.y = pack_f16x2(o[2], o[3]); }
         *reinterpret_cast<uint2*>(y + (row * C + idx * 4L) * 2) = pk;
       }
     }
@@ -432,11 +461,11 @@ extern "C" int cft_layernorm(const float* x, const float* gamma, const float* be
                              long rows, int C, float eps, int out_dtype, void* stream) {
   CFT_REQUIRE(x && gamma && beta && y, "cft_layernorm: null pointer");
   CFT_REQUIRE(C % 4 == 0 && C >= 4 && C <= 4096, "cft_layernorm: C must be a multiple of 4 and <= 4096");
-  CFT_REQUIRE(out_dtype == CFT_BF16 || out_dtype == CFT_F32, "cft_layernorm: bad out dtype");
+  CFT_REQUIRE(cft_is_dtype(out_dtype), "cft_layernorm: bad out dtype");
   CFT_REQUIRE(rows > 0, "cft_layernorm: rows must be positive");
   const int grid = (int)((rows + 3) / 4);
   const int nv = C / 4;
-  const int of32 = out_dtype == CFT_F32;
+  const int of32 = out_dtype;
   if (nv <= 64 * 2)
     hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, as_stream(stream), x, gamma, beta, (unsigned char*)y, rows, C, eps, of32);
   else if (nv <= 64 * 5)
@@ -499,20 +528,16 @@ extern "C" int cft_gpt_upsample_add(const float* tokens, int s, const void* base
                                     void* out, int ldo, int ooff, int B, int H, int W, int C,
                                     int dtype, void* stream) {
   CFT_REQUIRE(tokens && out, "cft_gpt_upsample_add: null pointer");
-  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F32, "cft_gpt_upsample_add: bad dtype");
+  CFT_REQUIRE(cft_is_dtype(dtype), "cft_gpt_upsample_add: bad dtype");
   CFT_REQUIRE(s == 0 || s == 1, "cft_gpt_upsample_add: stream index must be 0 or 1");
-  const int ge = dtype == CFT_BF16 ? 8 : 4, es = dtype == CFT_BF16 ? 2 : 4;
+  const int ge = cft_granule(dtype), es = cft_elem_size(dtype);
   CFT_REQUIRE(C % ge == 0 && ldo % ge == 0 && ooff % ge == 0 && (base == nullptr || (ldb % ge == 0 && boff % ge == 0)), "cft_gpt_upsample_add: not granule aligned");
   CFT_REQUIRE(C % 4 == 0 && (long)B * H < (1L << 31), "cft_gpt_upsample_add: C must be a multiple of 4");
   const int grid = B * H;
   const size_t smem = (size_t)8 * C * sizeof(float);
   CFT_REQUIRE(smem <= 64 * 1024, "cft_gpt_upsample_add: C too large for the LDS row (C <= 2048)");
-  if (dtype == CFT_BF16)
-    hipLaunchKernelGGL(gpt_upsample_add_kernel<uint16_t>, dim3(grid), dim3(256), smem, as_stream(stream), tokens, s, (const unsigned char*)base, (long)ldb * es, (long)boff * es,
-                       (unsigned char*)out, (long)ldo * es, (long)ooff * es, B, H, W, C);
-  else
-    hipLaunchKernelGGL(gpt_upsample_add_kernel<float>, dim3(grid), dim3(256), smem, as_stream(stream), tokens, s, (const unsigned char*)base, (long)ldb * es, (long)boff * es,
-                       (unsigned char*)out, (long)ldo * es, (long)ooff * es, B, H, W, C);
+  CFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(gpt_upsample_add_kernel<T>, dim3(grid), dim3(256), smem, as_stream(stream), tokens, s, (const unsigned char*)base, (long)ldb * es, (long)boff * es,
+                                                   (unsigned char*)out, (long)ldo * es, (long)ooff * es, B, H, W, C));
   return cft_check_launch("gpt_upsample_add_kernel");
 }
 

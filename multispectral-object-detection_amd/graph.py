@@ -27,6 +27,7 @@ class CapturedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.pred, self.raw = model.forward_once(self.rgb, self.ir)
+        self.weights_key = model.weights_key()     # Model.forward drops the graph when the weights change
 
     def replay(self, rgb, ir):
         self.rgb.copy_(rgb, non_blocking=True)

@@ -85,8 +85,23 @@ def resolve(x):
 
 
 def _cache_key(module, dtype, device):
-    vers = tuple(int(p._version) for p in module.parameters()) + tuple(int(b._version) for b in module.buffers())
+    """Identity of the packed weights: dtype, device and, per parameter/buffer, (storage address, in-place
+    version).  ``load_state_dict``, ``.to()``, ``.half()`` and optimiser-style in-place updates all change it;
+    edits through ``tensor.data`` do not bump ``_version`` - call ``invalidate_packed`` after those."""
+    vers = tuple((int(p.data_ptr()), int(p._version)) for p in module.parameters()) \
+        + tuple((int(b.data_ptr()), int(b._version)) for b in module.buffers())
     return (dtype, str(device), vers)
+
+
+def invalidate_packed(root):
+    """Drop the kernel-side weight copies of every module under ``root`` (they are rebuilt on the next forward)
+    and, if ``root`` owns captured HIP graphs, those too - a graph replays the weight buffers it was captured
+    with."""
+    for m in root.modules():
+        m.__dict__.pop("_cft_cache", None)
+        if "_graphs" in m.__dict__:
+            m.__dict__["_graphs"].clear()
+        m.__dict__.pop("_wlist", None)
 
 
 class _Packed(nn.Module):
@@ -116,6 +131,11 @@ def _folded(conv_module):
         return ops.fold_bn(conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
     bias = conv.bias.float() if conv.bias is not None else torch.zeros(conv.out_channels, device=conv.weight.device)
     return conv.weight.float(), bias
+
+
+def _f32(t, device):
+    """Contiguous fp32 device copy of a parameter/buffer that a kernel reads through a raw float pointer."""
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
 def _act_code(act):
@@ -346,7 +366,7 @@ class SelfAttention(_Packed):
 
     @staticmethod
     def padded_head(dk, dtype):
-        step = 32 if dtype == torch.bfloat16 else 16
+        step = 16 if dtype == torch.float32 else 32
         return ((dk + step - 1) // step) * step
 
     def _pack(self, dtype, device):
@@ -398,19 +418,20 @@ class myTransformerBlock(_Packed):
     def _pack(self, dtype, device):
         fc1 = ops.pack_conv(self.mlp[0].weight, self.mlp[0].bias, dtype, device=device)
         fc2 = ops.pack_conv(self.mlp[2].weight, self.mlp[2].bias, dtype, device=device)
-        return fc1, fc2
+        ln = [_f32(t, device) for t in (self.ln_input.weight, self.ln_input.bias, self.ln_output.weight, self.ln_output.bias)]
+        return fc1, fc2, ln
 
     def forward(self, x, compute_dtype=torch.bfloat16):
-        fc1, fc2 = self._packed(compute_dtype, x.device)
-        y = ops.layernorm(x, self.ln_input.weight, self.ln_input.bias, compute_dtype, self.ln_input.eps)
+        fc1, fc2, ln = self._packed(compute_dtype, x.device)
+        y = ops.layernorm(x, ln[0], ln[1], compute_dtype, self.ln_input.eps)
         self.sa(y, residual=x)                                   # x += out_proj(attention(LN(x)))
-        y = ops.layernorm(x, self.ln_output.weight, self.ln_output.bias, compute_dtype, self.ln_output.eps)
+        y = ops.layernorm(x, ln[2], ln[3], compute_dtype, self.ln_output.eps)
         hid = ops.linear(y, fc1, act=ACT_GELU)
         ops.linear(hid, fc2, residual=x, out=x, out_dtype=torch.float32)  # x += fc2(gelu(fc1(LN(x))))
         return x
 
 
-class GPT(nn.Module):
+class GPT(_Packed):
     """Cross-modality fusion transformer (reference models/common.py:549-639)."""
 
     def __init__(self, d_model, h=8, block_exp=4, n_layer=8, vert_anchors=8, horz_anchors=8,
@@ -439,6 +460,9 @@ class GPT(nn.Module):
             module.bias.data.zero_()
             module.weight.data.fill_(1.0)
 
+    def _pack(self, dtype, device):   # fp32 copies of what the kernels read through raw pointers (fp16 after model.half())
+        return _f32(self.pos_emb, device), _f32(self.ln_f.weight, device), _f32(self.ln_f.bias, device)
+
     def forward(self, x):
         if self.training:
             raise RuntimeError("GPT: only the inference forward is implemented (call model.eval())")
@@ -450,9 +474,10 @@ class GPT(nn.Module):
             raise ValueError("GPT: the two streams must have the same shape and dtype")
         B, C, H, W = rgb.shape
         dtype = rgb.dtype
-        tok = ops.gpt_tokenize(rgb, ir, self.pos_emb)            # fp32 [B,128,C], pos_emb added
+        pos_emb, lnf_w, lnf_b = self._packed(dtype, rgb.device)
+        tok = ops.gpt_tokenize(rgb, ir, pos_emb)                 # fp32 [B,128,C], pos_emb added
         t2 = tok.view(B * 128, C)
         for blk in self.trans_blocks:
             blk(t2, dtype)
-        tok_f = ops.layernorm(t2, self.ln_f.weight, self.ln_f.bias, torch.float32, self.ln_f.eps).view(B, 128, C)
+        tok_f = ops.layernorm(t2, lnf_w, lnf_b, torch.float32, self.ln_f.eps).view(B, 128, C)
         return PendingBilinear(tok_f, 0, H, W, dtype), PendingBilinear(tok_f, 1, H, W, dtype)

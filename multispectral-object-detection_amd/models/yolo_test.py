@@ -10,7 +10,8 @@ Drop-in for the reference's ``models/yolo_test.py`` - which, despite its name, i
 
 What differs is underneath: every layer runs hand-written gfx950 kernels on NHWC activations
 (``models/common.py`` here), the compute precision is a model property
-(``set_compute_dtype(torch.bfloat16 | torch.float32)``; images stay fp32 NCHW at the boundary), and
+(``set_compute_dtype(torch.bfloat16 | torch.float16 | torch.float32)``; ``model.half()`` selects fp16 like it
+does in the reference's callers, test.py:66-68; images arrive fp32 / fp16 / uint8 NCHW at the boundary), and
 the whole forward can be captured once into a HIP graph (``capture``) so that the ~600 kernel
 launches of yolov5l+CFTx3 cost one graph launch.
 """
@@ -24,7 +25,7 @@ import torch.nn as nn
 
 from .. import ops
 from .common import (GPT, SPP, Add, Add2, Bottleneck, C3, Concat, Conv, Focus, Upsample, _Packed, resolve,
-                     ACT_NONE)
+                     ACT_NONE, invalidate_packed)
 
 logger = logging.getLogger(__name__)
 
@@ -60,18 +61,18 @@ class Detect(_Packed):
         self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)
 
     def _pack(self, dtype, device):
-        return [ops.pack_conv(m.weight, m.bias, dtype, device=device) for m in self.m]
+        anchors_px = self.anchor_grid.detach().to(device=device, dtype=torch.float32).view(self.nl, -1).contiguous()
+        return [ops.pack_conv(m.weight, m.bias, dtype, device=device) for m in self.m], anchors_px
 
     def forward(self, x):
         if self.training or self.export:
             raise RuntimeError("Detect: only the inference branch (models/yolo_test.py:50-59) is implemented")
         x = [resolve(t) for t in x]
-        packed = self._packed(x[0].dtype, x[0].device)
+        packed, anchors_px = self._packed(x[0].dtype, x[0].device)
         B = x[0].shape[0]
         dev = x[0].device
         rows = [self.na * t.shape[2] * t.shape[3] for t in x]
         pred = torch.empty((B, sum(rows), self.no), dtype=torch.float32, device=dev)
-        anchors_px = self.anchor_grid.view(self.nl, -1).float().contiguous()
         raws, row0 = [], 0
         for i in range(self.nl):
             logits = ops.conv2d(x[i], packed[i], ACT_NONE, out_dtype=torch.float32)   # [B, pad8(na*no), ny, nx]
@@ -186,8 +187,44 @@ class Model(nn.Module):
         """Un-pickling a checkpoint written by the reference restores only the reference's attributes."""
         super().__setstate__(state)
         self.__dict__.setdefault("_graphs", {})
-        self.__dict__.setdefault("compute_dtype", torch.bfloat16)
+        if "compute_dtype" not in self.__dict__:     # a reference pickle: compute in the precision its weights carry
+            p = next(self.parameters(), None)       # (checkpoints are saved .half(), train.py:852; attempt_load then .float()s)
+            self.__dict__["compute_dtype"] = p.dtype if p is not None and p.dtype in ops.COMPUTE_DTYPES else torch.float32
         self.__dict__.setdefault("overlap_streams", True)
+
+    # ---- weight-change tracking (ADVICE r1): a captured graph replays the packed buffers of capture time -------
+    def invalidate_packed(self):
+        """Forget packed weights and captured graphs; call after editing weights through ``.data``."""
+        invalidate_packed(self)
+        return self
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        invalidate_packed(self)
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        """``.to()/.cuda()/.half()/.float()`` move or cast the parameters: packed copies and graphs are stale."""
+        out = super()._apply(fn, *args, **kwargs)
+        invalidate_packed(self)
+        return out
+
+    def half(self):
+        """Reference callers switch to fp16 inference with ``model.half()`` (test.py:66-68, detect_twostream.py:
+        40-41): parameters become fp16 as in ``nn.Module.half`` and the kernels compute in fp16 (fp32 accumulate)."""
+        super().half()
+        return self.set_compute_dtype(torch.float16)
+
+    def float(self):
+        """``attempt_load(...).float()``: fp32 parameters; a model put into fp16 by ``half()`` returns to fp32 compute."""
+        super().float()
+        if self.compute_dtype == torch.float16:
+            self.set_compute_dtype(torch.float32)
+        return self
+
+    def bfloat16(self):
+        super().bfloat16()
+        return self.set_compute_dtype(torch.bfloat16)
 
     # ---- reference-compatible API -----------------------------------------------------------
     def forward(self, x, x2, augment=False, profile=False):
@@ -203,8 +240,19 @@ class Model(nn.Module):
         key = (tuple(x.shape), self.compute_dtype, x.dtype)
         g = self._graphs.get(key)
         if g is not None:
-            return g.replay(x, x2)
+            if g.weights_key == self.weights_key():
+                return g.replay(x, x2)
+            self._graphs.clear()            # weights changed since capture: the graph would replay the old ones
         return self.forward_once(x, x2, profile)
+
+    def weights_key(self):
+        """Cheap fingerprint (~0.15 ms) of every parameter/buffer's in-place version counter, compared at replay
+        time.  Re-allocations (``.to()``, ``.half()``, ``load_state_dict``, ``fuse()``) go through
+        ``invalidate_packed`` instead, which also drops the cached tensor list used here."""
+        ws = self.__dict__.get("_wlist")
+        if ws is None:
+            ws = self.__dict__["_wlist"] = list(self.parameters()) + list(self.buffers())
+        return hash(tuple(t._version for t in ws))
 
     def stream_lanes(self):
         """Lane (HIP stream) of every layer: the IR backbone - everything reachable from an ``f == -4``
@@ -276,8 +324,8 @@ class Model(nn.Module):
                     if (type(layers[j]) is Conv or isinstance(layers[j], (C3, Add))) and j not in plan and layers[j].f != -4:
                         plan[j] = (i, off, c, sum(chans))
                     off += c
-        except Exception:                     # foreign module graph: no plan, Concat copies as before
-            plan = {}
+        except (IndexError, KeyError, TypeError, AttributeError):   # foreign module graph (bad `from` index, unknown
+            plan = {}                                               # module type): no plan, Concat copies as before
         self.__dict__["_concat_plan"] = plan
         return plan
 
@@ -365,7 +413,7 @@ class Model(nn.Module):
                 fused.bias.copy_(b.detach())
                 m.conv = fused
                 delattr(m, "bn")
-        self._graphs.clear()
+        invalidate_packed(self)
         return self
 
     def info(self, verbose=False, img_size=640):
@@ -374,10 +422,13 @@ class Model(nn.Module):
 
     # ---- MI355X-specific ---------------------------------------------------------------------
     def set_compute_dtype(self, dtype):
-        """bf16 (default; fp32 accumulation, fp32 CFT residual stream and logits) or fp32 (exact-fp32
-        MFMA path used for the 1e-3 tolerance configuration)."""
-        if dtype not in (torch.bfloat16, torch.float32):
-            raise TypeError("compute dtype must be torch.bfloat16 or torch.float32")
+        """bf16 (default) or fp16 - both with fp32 accumulation, fp32 CFT residual stream and fp32 logits; fp16 is
+        the reference's own GPU precision and the 16-bit type that meets the 1e-2 parity bound - or
+        fp32 (exact-fp32 MFMA path used for the 1e-3 tolerance configuration)."""
+        if dtype not in ops.COMPUTE_DTYPES:
+            raise TypeError("compute dtype must be torch.bfloat16, torch.float16 or torch.float32")
+        if dtype != self.compute_dtype:
+            self._graphs.clear()
         self.compute_dtype = dtype
         for m in self.modules():
             if isinstance(m, Focus):

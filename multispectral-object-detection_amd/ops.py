@@ -13,15 +13,20 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_SILU, CFT_BF16, CFT_F32  # noqa: F401
+from ._lib import ACT_GELU, ACT_NONE, ACT_SILU, CFT_BF16, CFT_F16, CFT_F32  # noqa: F401
+
+
+COMPUTE_DTYPES = (torch.bfloat16, torch.float16, torch.float32)
 
 
 def _dt(dtype):
     if dtype == torch.bfloat16:
         return CFT_BF16
+    if dtype == torch.float16:
+        return CFT_F16
     if dtype == torch.float32:
         return CFT_F32
-    raise TypeError(f"compute dtype must be torch.bfloat16 or torch.float32, got {dtype}")
+    raise TypeError(f"compute dtype must be torch.bfloat16, torch.float16 or torch.float32, got {dtype}")
 
 
 def _stream():
@@ -35,7 +40,7 @@ def _require_cuda(t, what):
 
 
 def granule(dtype):
-    return 8 if dtype == torch.bfloat16 else 4
+    return 4 if dtype == torch.float32 else 8
 
 
 def new_nhwc(B, H, W, C, dtype, device):
@@ -43,17 +48,34 @@ def new_nhwc(B, H, W, C, dtype, device):
     return torch.empty((B, H, W, C), dtype=dtype, device=device).permute(0, 3, 1, 2)
 
 
+def to_nhwc(x, dtype=None, cpad=None):
+    """Any strided [B,C,H,W] fp32/bf16/half tensor -> fresh NHWC buffer in ``dtype`` with the channel count
+    padded to ``cpad`` (default: next granule multiple; padding channels zero) - the cft_to_nhwc kernel."""
+    _require_cuda(x, "to_nhwc")
+    B, C, H, W = x.shape
+    dtype = dtype or x.dtype
+    ge = granule(dtype)
+    cp = cpad or ((C + ge - 1) // ge) * ge
+    y = new_nhwc(B, H, W, cp, dtype, x.device)
+    st = _lib.load().cft_to_nhwc(x.data_ptr(), _dt(x.dtype), x.stride(0), x.stride(1), x.stride(2), x.stride(3),
+                                 y.data_ptr(), cp, 0, B, C, H, W, _dt(dtype), _stream())
+    _lib.check(st, "cft_to_nhwc")
+    return y
+
+
 def as_nhwc(x):
-    """Return (x', ld): x' has NHWC memory (copying only if x does not already), ld = channels/pixel."""
+    """Return (x', ld): x' has NHWC memory, ld = channels/pixel.  A tensor in another layout (e.g. a plain NCHW
+    tensor handed to a module from outside the network) is converted by the cft_to_nhwc kernel; its channel
+    count must already be a granule multiple (the consumer's packed weights fix the channel count)."""
     B, C, H, W = x.shape
     ld = x.stride(3)
     ok = x.stride(1) == 1 and ld >= C and x.stride(2) == W * ld and x.stride(0) == H * W * ld
     ge = granule(x.dtype)
     ok = ok and ld % ge == 0 and (x.storage_offset() % ge == 0)
     if not ok:
-        y = new_nhwc(B, H, W, C, x.dtype, x.device)
-        y.copy_(x)
-        return y, C
+        if C % ge:
+            raise ValueError(f"as_nhwc: {C} channels is not a multiple of the {ge}-element granule")
+        return to_nhwc(x), C
     return x, ld
 
 
@@ -172,7 +194,7 @@ def conv2d(x, pk, act, residual=None, out=None, out_dtype=None):
 
 def bottleneck_fusable(x, pk1, pk2, act1, act2):
     """True when ``bottleneck`` below can run as the single cft_bottleneck kernel."""
-    return (x.dtype == torch.bfloat16 and act1 == ACT_SILU and act2 == ACT_SILU
+    return (x.dtype in (torch.bfloat16, torch.float16) and act1 == ACT_SILU and act2 == ACT_SILU
             and pk1.k == 1 and pk1.s == 1 and pk2.k == 3 and pk2.s == 1
             and pk1.cin == pk1.n == pk2.cin == pk2.n == 64 and x.shape[1] == 64)
 
@@ -191,7 +213,7 @@ def bottleneck(x, pk1, pk2, shortcut, out=None):
     lib = _lib.load()
     args = (x.data_ptr(), ldx, 0, pk1.w.data_ptr(), pk1.kpad, pk1.bias.data_ptr() if pk1.bias is not None else None,
             pk2.w.data_ptr(), pk2.kpad, pk2.bias.data_ptr() if pk2.bias is not None else None,
-            out.data_ptr(), ldy, 0, B, H, W, C, 1 if shortcut else 0, _stream())
+            out.data_ptr(), ldy, 0, B, H, W, C, 1 if shortcut else 0, _dt(x.dtype), _stream())
     if _launch_log is None:
         st = lib.cft_bottleneck(*args)
     else:   # counted with the GEMM family: both convolutions' FLOPs, one launch
@@ -242,11 +264,21 @@ def focus_s2d(img, dtype):
                                           B, H, W, 1.0 / 255.0, _dt(dtype), _stream())
         _lib.check(st, "cft_focus_s2d_u8")
         return out
-    if img.dtype != torch.float32 or not img.is_contiguous():
-        img = img.float().contiguous()
     B, C, H, W = img.shape
     if C != 3:
         raise ValueError(f"focus_s2d: expected 3 input channels, got {C}")
+    if img.dtype != torch.float32 or not img.is_contiguous():
+        # half / bf16 / strided images -> contiguous fp32 NCHW with the conversion kernel: seen as an "NHWC" problem
+        # with (batch*channel, row, 1 pixel, W "channels") the output is exactly the contiguous NCHW image
+        if img.dtype not in COMPUTE_DTYPES:
+            raise TypeError(f"focus_s2d: unsupported image dtype {img.dtype}")
+        if img.stride(0) != 3 * img.stride(1) or W % 4:
+            raise ValueError("focus_s2d: non-fp32 / strided images need uniform batch/channel strides and W % 4 == 0")
+        flat = torch.empty((B, 3, H, W), dtype=torch.float32, device=img.device)
+        st = _lib.load().cft_to_nhwc(img.data_ptr(), _dt(img.dtype), img.stride(1), img.stride(3), img.stride(2), 0,
+                                     flat.data_ptr(), W, 0, B * 3, W, H, 1, CFT_F32, _stream())
+        _lib.check(st, "cft_to_nhwc(image)")
+        img = flat
     out = new_nhwc(B, H // 2, W // 2, 16, dtype, img.device)
     st = _lib.load().cft_focus_s2d(img.data_ptr(), out.data_ptr(), B, H, W, _dt(dtype), _stream())
     _lib.check(st, "cft_focus_s2d")
@@ -260,12 +292,11 @@ def focus_conv(img, pk, act, dtype):
     _require_cuda(img, "focus_conv")
     if img.dim() != 4 or img.shape[1] != 3:
         raise ValueError(f"focus_conv: expected a [B,3,H,W] image batch, got {tuple(img.shape)}")
-    fusable = (dtype == torch.bfloat16 and pk.k == 3 and pk.s == 1 and pk.cin == 16 and pk.kpad == 192
-               and pk.n in (32, 48, 64, 80) and act in (ACT_NONE, ACT_SILU))
+    fusable = (dtype in (torch.bfloat16, torch.float16) and pk.k == 3 and pk.s == 1 and pk.cin == 16 and pk.kpad == 192
+               and pk.n in (32, 48, 64, 80) and act in (ACT_NONE, ACT_SILU)
+               and (img.dtype in (torch.uint8, torch.float32) or (img.dtype == torch.float16 and dtype == torch.float16)))
     if not fusable:
         return conv2d(focus_s2d(img, dtype), pk, act)
-    if img.dtype != torch.uint8 and img.dtype != torch.float32:
-        img = img.float()
     es = img.element_size()
     if img.stride(3) != 1 or any(img.stride(i) % 2 for i in range(3)) or img.data_ptr() % (2 * es):
         img = img.contiguous()
@@ -273,11 +304,12 @@ def focus_conv(img, pk, act, dtype):
     if H % 2 or W % 2:
         raise ValueError("focus_conv: H and W must be even")
     u8 = img.dtype == torch.uint8
+    kind = 1 if u8 else (2 if img.dtype == torch.float16 else 0)
     out = new_nhwc(B, H // 2, W // 2, pk.n, dtype, img.device)
     lib = _lib.load()
-    args = (img.data_ptr(), 1 if u8 else 0, img.stride(0), img.stride(1), img.stride(2), 1.0 / 255.0 if u8 else 1.0,
+    args = (img.data_ptr(), kind, img.stride(0), img.stride(1), img.stride(2), 1.0 / 255.0 if u8 else 1.0,
             pk.w.data_ptr(), pk.kpad, pk.bias.data_ptr() if pk.bias is not None else None, out.data_ptr(),
-            _view_ld(out, "focus_conv out"), 0, B, H, W, pk.n, act, _stream())
+            _view_ld(out, "focus_conv out"), 0, B, H, W, pk.n, act, _dt(dtype), _stream())
     if _launch_log is None:
         st = lib.cft_focus_conv(*args)
     else:   # counted with the GEMM family (it is the same implicit-GEMM MFMA work, on a dedicated kernel)

@@ -101,7 +101,7 @@ def test_pack_conv_layout(dtype):
 def test_c_abi_exports_every_declared_symbol():
     """The shared library must load (no GPU needed) and export exactly what include/cft_hip.h declares."""
     lib = _lib.load()
-    assert lib.cft_abi_version() == 1
+    assert lib.cft_abi_version() == 2
     header = open(os.path.join(ROOT, "include", "cft_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(cft_\w+)\s*\(", header, re.M))
     assert declared == set(_lib.SIGNATURES) | {"cft_last_error"}, declared ^ (set(_lib.SIGNATURES) | {"cft_last_error"})
@@ -117,18 +117,18 @@ def test_bad_arguments_return_error_codes_without_gpu():
     st = lib.cft_layernorm(1, 1, 1, 1, 4, 6, 1e-5, 0, None)     # C not a multiple of 4; rejected before any launch
     assert st == -1
     # fused Focus: only 32/48/64/80 output channels, weights packed [n][192], even pointer/strides
-    st = lib.cft_focus_conv(16, 0, 3 * 64 * 64, 64 * 64, 64, 1.0, 16, 192, None, 16, 40, 0, 1, 64, 64, 40, 1, None)
+    st = lib.cft_focus_conv(16, 0, 3 * 64 * 64, 64 * 64, 64, 1.0, 16, 192, None, 16, 40, 0, 1, 64, 64, 40, 1, 0, None)
     assert st == -1 and b"n must be 32, 48, 64 or 80" in lib.cft_last_error()
-    st = lib.cft_focus_conv(16, 0, 3 * 64 * 64, 64 * 64, 64, 1.0, 16, 160, None, 16, 64, 0, 1, 64, 64, 64, 1, None)
+    st = lib.cft_focus_conv(16, 0, 3 * 64 * 64, 64 * 64, 64, 1.0, 16, 160, None, 16, 64, 0, 1, 64, 64, 64, 1, 0, None)
     assert st == -1 and b"[n][192]" in lib.cft_last_error()
-    st = lib.cft_focus_conv(17, 1, 3 * 64 * 64, 64 * 64, 64, 1.0 / 255, 16, 192, None, 16, 64, 0, 1, 64, 64, 64, 1, None)
+    st = lib.cft_focus_conv(17, 1, 3 * 64 * 64, 64 * 64, 64, 1.0 / 255, 16, 192, None, 16, 64, 0, 1, 64, 64, 64, 1, 0, None)
     assert st == -1 and b"pixel-pair" in lib.cft_last_error()
     # fused Bottleneck: 64 channels only, and never in place (it reads a halo of x)
-    st = lib.cft_bottleneck(4096, 128, 0, 16, 128, None, 16, 1152, None, 1 << 20, 128, 0, 1, 8, 8, 128, 1, None)
+    st = lib.cft_bottleneck(4096, 128, 0, 16, 128, None, 16, 1152, None, 1 << 20, 128, 0, 1, 8, 8, 128, 1, 0, None)
     assert st == -1 and b"64 channels" in lib.cft_last_error()
-    st = lib.cft_bottleneck(4096, 64, 0, 16, 64, None, 16, 576, None, 4096, 64, 0, 1, 8, 8, 64, 1, None)
+    st = lib.cft_bottleneck(4096, 64, 0, 16, 64, None, 16, 576, None, 4096, 64, 0, 1, 8, 8, 64, 1, 0, None)
     assert st == -1 and b"overlaps the input" in lib.cft_last_error()
-    st = lib.cft_bottleneck(4096, 128, 0, 16, 64, None, 16, 576, None, 4096 + 64, 128, 0, 1, 8, 8, 64, 1, None)
+    st = lib.cft_bottleneck(4096, 128, 0, 16, 64, None, 16, 576, None, 4096 + 64, 128, 0, 1, 8, 8, 64, 1, 0, None)
     assert st == -1 and b"overlaps" in lib.cft_last_error()       # slices of one buffer that share channels [32,64)
 
 
@@ -172,7 +172,7 @@ torch.save({{"model": m, "ema": None, "epoch": 3}}, {str(ck)!r})
     subprocess.run([sys.executable, "-c", script], check=True, capture_output=True)
     from msod_amd import compat
     model = compat.attempt_load(str(ck), map_location="cpu")
-    assert type(model).__module__.startswith("msod_amd") and model.compute_dtype == torch.bfloat16
+    assert type(model).__module__.startswith("msod_amd") and model.compute_dtype == torch.float32   # .float(), as the reference
     assert type(model.model[-1]).__name__ == "Detect" and not hasattr(model.model[1], "bn")     # fused
     assert all(p.dtype == torch.float32 for p in model.parameters())
     ups = [m for m in model.model if isinstance(m, torch.nn.Upsample)]
