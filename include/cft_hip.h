@@ -184,15 +184,15 @@ int cft_detect_decode(const float* logits, int ldl, float* raw, float* pred, con
 /*
  * Batched NMS on the decoded predictions (utils/general.py:455-543 `non_max_suppression`, incl. the
  * torchvision.ops.nms call at :527): per image keep rows with obj > conf_thres, conf = obj*cls, best class
- * (multi_label = 0) or every class above conf_thres (multi_label = 1), optional class filter (bit c of
- * class_mask = class c allowed; classes >= 64 always allowed), xywh -> xyxy, per-class greedy NMS (class
- * offset 4096 px unless agnostic) with IoU > iou_thres suppression, at most max_det detections.
+ * (multi_label = 0) or every class above conf_thres (multi_label = 1), optional class filter (class_allow:
+ * device array of no-5 bytes, non-zero = class kept, :505-506; NULL = all classes), xywh -> xyxy, the max_nms
+ * pre-truncation to the highest confidences (:469,:515-516; 0 = off), per-class greedy NMS (class offset
+ * 4096 px unless agnostic) with IoU > iou_thres suppression, at most max_det detections.
  *   pred    : float [B, rows, no]            dets : float [B, max_det, 6] (x1,y1,x2,y2,conf,cls), first counts[b] rows valid
  *   scratch : >= B * rows * (multi_label ? no-5 : 1) * 32 bytes of device memory
- * The reference's max_nms = 30000 pre-truncation is not applied (all candidates take part).
  */
 int cft_nms(const float* pred, int B, int rows, int no, float conf_thres, float iou_thres,
-            int agnostic, int multi_label, unsigned long long class_mask, int max_det,
+            int agnostic, int multi_label, const unsigned char* class_allow, int max_det, int max_nms,
             void* scratch, long scratch_bytes, float* dets, int* counts, void* stream);
 
 #ifdef __cplusplus

@@ -42,7 +42,7 @@ SIGNATURES = {
     "cft_layernorm": [_vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp],
     "cft_attention": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cft_gpt_upsample_add": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "cft_nms": [_vp, _i, _i, _i, _f, _f, _i, _i, _c.c_ulonglong, _i, _vp, _l, _vp, _vp, _vp],
+    "cft_nms": [_vp, _i, _i, _i, _f, _f, _i, _i, _vp, _i, _i, _vp, _l, _vp, _vp, _vp],
     "cft_detect_decode": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _l, _vp],
 }
 

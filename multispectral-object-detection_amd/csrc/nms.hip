@@ -4,6 +4,10 @@
 //   phase 1  candidate filter + compaction: obj > conf_thres, conf = obj * cls, best class (or every class
 //            above the threshold when multi_label), optional class filter, xywh -> xyxy, append to the
 //            image's scratch list (LDS atomic cursor);
+//   phase 1b the reference's `max_nms` pre-truncation (:469, :515-516): if more than max_nms candidates remain,
+//            only the max_nms highest confidences take part - an 8-bit-per-pass radix select of the max_nms-th
+//            score in LDS, then everything below it is dropped (candidates that TIE with that score all stay;
+//            the reference's unstable argsort leaves their order unspecified);
 //   phase 2  greedy selection: up to max_det rounds of {workgroup arg-max of the live scores, emit it,
 //            kill every live box whose IoU with it exceeds iou_thres}.  Boxes of different classes are
 //            separated by the reference's class offset (cls * 4096) unless agnostic.  This is exactly the
@@ -17,10 +21,12 @@ struct NmsCand { float x1, y1, x2, y2, score; int cls; int key; int pad; };   //
 __device__ __forceinline__ bool better(float s, int k, float s2, int k2) { return s > s2 || (s == s2 && k < k2); }
 
 __global__ void __launch_bounds__(1024) nms_kernel(const float* __restrict__ pred, int rows, int no, float conf_thres,
-                                                   float iou_thres, int agnostic, int multi_label, unsigned long long class_mask,
-                                                   int max_det, int cap, NmsCand* __restrict__ scratch, float* __restrict__ dets,
+                                                   float iou_thres, int agnostic, int multi_label, const unsigned char* __restrict__ class_allow,
+                                                   int max_det, int max_nms, int cap, NmsCand* __restrict__ scratch, float* __restrict__ dets,
                                                    int* __restrict__ counts) {
   __shared__ int s_n;
+  __shared__ unsigned s_hist[256];
+  __shared__ unsigned s_prefix, s_want;
   __shared__ float s_score[16];
   __shared__ int s_key[16], s_idx[16];
   __shared__ float s_box[4];
@@ -40,7 +46,7 @@ __global__ void __launch_bounds__(1024) nms_kernel(const float* __restrict__ pre
     if (multi_label) {
       for (int c = 0; c < nc; ++c) {
         const float conf = p[5 + c] * obj;
-        if (conf > conf_thres && (c >= 64 || ((class_mask >> c) & 1ull))) {
+        if (conf > conf_thres && (class_allow == nullptr || class_allow[c])) {
           const int i = atomicAdd(&s_n, 1);
           if (i < cap) C[i] = NmsCand{cx - hw, cy - hh, cx + hw, cy + hh, conf, c, r * nc + c, 0};
         }
@@ -52,7 +58,7 @@ __global__ void __launch_bounds__(1024) nms_kernel(const float* __restrict__ pre
         const float conf = p[5 + c] * obj;
         if (conf > best) { best = conf; bc = c; }
       }
-      if (best > conf_thres && (bc >= 64 || ((class_mask >> bc) & 1ull))) {
+      if (best > conf_thres && (class_allow == nullptr || class_allow[bc])) {
         const int i = atomicAdd(&s_n, 1);
         if (i < cap) C[i] = NmsCand{cx - hw, cy - hh, cx + hw, cy + hh, best, bc, r, 0};
       }
@@ -61,6 +67,36 @@ __global__ void __launch_bounds__(1024) nms_kernel(const float* __restrict__ pre
   __syncthreads();
   const int n = s_n < cap ? s_n : cap;
   __threadfence_block();
+  // ---- phase 1b: keep only the max_nms best scores (scores are positive floats: their bit patterns order like uints)
+  if (max_nms > 0 && n > max_nms) {
+    if (tid == 0) { s_prefix = 0u; s_want = (unsigned)max_nms; }
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 256) s_hist[tid] = 0u;
+      __syncthreads();
+      const unsigned prefix = s_prefix;
+      const unsigned hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+      for (int i = tid; i < n; i += 1024) {
+        const unsigned u = __float_as_uint(C[i].score);
+        if ((u & hi_mask) == prefix) atomicAdd(&s_hist[(u >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {   // walk the digits from the top: the bucket in which the want-th largest score falls
+        unsigned want = s_want, d = 255u;
+        for (;; --d) {
+          if (s_hist[d] >= want || d == 0u) break;
+          want -= s_hist[d];
+        }
+        s_want = want;
+        s_prefix = prefix | (d << shift);
+      }
+      __syncthreads();
+    }
+    const unsigned kth = s_prefix;     // bit pattern of the max_nms-th largest score
+    for (int i = tid; i < n; i += 1024)
+      if (__float_as_uint(C[i].score) < kth) C[i].score = -1.f;
+    __syncthreads();
+    __threadfence_block();
+  }
   // ---- phase 2 ----
   const float max_wh = 4096.f;
   int kept = 0;
@@ -117,14 +153,14 @@ __global__ void __launch_bounds__(1024) nms_kernel(const float* __restrict__ pre
 }
 
 extern "C" int cft_nms(const float* pred, int B, int rows, int no, float conf_thres, float iou_thres,
-                       int agnostic, int multi_label, unsigned long long class_mask, int max_det,
+                       int agnostic, int multi_label, const unsigned char* class_allow, int max_det, int max_nms,
                        void* scratch, long scratch_bytes, float* dets, int* counts, void* stream) {
   CFT_REQUIRE(pred && scratch && dets && counts, "cft_nms: null pointer");
-  CFT_REQUIRE(B > 0 && rows > 0 && no >= 6 && max_det > 0, "cft_nms: bad shape (needs at least one class)");
+  CFT_REQUIRE(B > 0 && rows > 0 && no >= 6 && max_det > 0 && max_nms >= 0, "cft_nms: bad shape (needs at least one class)");
   const int nc = no - 5;
   const long cap = (long)rows * (multi_label ? nc : 1);
   CFT_REQUIRE(cap < (1L << 30) && scratch_bytes >= (long)B * cap * (long)sizeof(NmsCand), "cft_nms: scratch too small (need B*rows*(multi_label?nc:1)*32 bytes)");
   hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), 0, as_stream(stream), pred, rows, no, conf_thres, iou_thres, agnostic, multi_label,
-                     class_mask, max_det, (int)cap, (NmsCand*)scratch, dets, counts);
+                     class_allow, max_det, max_nms, (int)cap, (NmsCand*)scratch, dets, counts);
   return cft_check_launch("nms_kernel");
 }

@@ -7,6 +7,7 @@ train.py:654-658,993); this is the new collective of BASELINE.json's north_star.
 forward is independent in eval mode, so there is no other communication.
 """
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -39,24 +40,37 @@ def shard_batch(x, rank, world):
     return x[lo:hi]
 
 
-def all_gather_detections(pred, world=None, group=None):
+def all_gather_detections(pred, world=None, group=None, like=None):
     """pred [B_local, rows, no] -> [sum(B_local), rows, no] on every rank, in rank order.
-    Equal local batches use one all_gather_into_tensor; ragged ones pad to the max batch."""
+    Equal local batches use one all_gather_into_tensor; ragged ones pad to the max batch.  A rank whose shard is
+    EMPTY (global batch < world size) passes ``pred=None`` and ``like=(ndim, dtype, device)``: it learns the row
+    shape from the other ranks and still takes part in every collective (no rank may skip one - ADVICE r1)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return pred
     world = world or dist.get_world_size(group)
-    pred = pred.contiguous()
-    nloc = torch.tensor([pred.shape[0]], device=pred.device, dtype=torch.int64)
-    sizes = [torch.zeros_like(nloc) for _ in range(world)]
-    dist.all_gather(sizes, nloc, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    if pred is not None:
+        pred = pred.contiguous()
+        ndim, dtype, device = pred.dim(), pred.dtype, pred.device
+        shape = list(pred.shape)
+    else:
+        ndim, dtype, device = like
+        shape = [0] * ndim
+    mine = torch.tensor(shape, device=device, dtype=torch.int64)
+    shapes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(shapes, mine, group=group)
+    shapes = [[int(v) for v in t.tolist()] for t in shapes]
+    sizes = [t[0] for t in shapes]
+    trail = tuple(max(t[d] for t in shapes) for d in range(1, ndim))
     bmax = max(sizes)
+    if bmax == 0:
+        return torch.empty((0,) + trail, dtype=dtype, device=device)
     if min(sizes) == bmax:
-        out = torch.empty((world * bmax,) + tuple(pred.shape[1:]), dtype=pred.dtype, device=pred.device)
+        out = torch.empty((world * bmax,) + trail, dtype=dtype, device=device)
         dist.all_gather_into_tensor(out, pred, group=group)
         return out
-    padded = torch.zeros((bmax,) + tuple(pred.shape[1:]), dtype=pred.dtype, device=pred.device)
-    padded[:pred.shape[0]] = pred
+    padded = torch.zeros((bmax,) + trail, dtype=dtype, device=device)
+    if pred is not None and pred.shape[0]:
+        padded[:pred.shape[0]] = pred
     chunks = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(chunks, padded, group=group)
     return torch.cat([c[:n] for c, n in zip(chunks, sizes)], 0)
@@ -74,8 +88,12 @@ def gather_equal(pred, out=None, group=None):
 
 
 def sharded_forward(model, rgb, ir, rank, world, group=None):
-    """Run ``model`` on this rank's shard of the global batch and gather every rank's detections."""
-    pred, _ = model(shard_batch(rgb, rank, world), shard_batch(ir, rank, world))
+    """Run ``model`` on this rank's shard of the global batch and gather every rank's detections.  A rank with an
+    empty shard (batch < world) skips the forward but not the collective."""
+    a, b = shard_batch(rgb, rank, world), shard_batch(ir, rank, world)
+    if a.shape[0] == 0:
+        return all_gather_detections(None, world, group, like=(3, torch.float32, rgb.device))
+    pred, _ = model(a, b)
     return all_gather_detections(pred, world, group)
 
 
@@ -84,11 +102,56 @@ def sharded_detect(model, rgb, ir, rank, world, nms, group=None):
     [B_local, max_det, 6] + counts (0.46 MB per rank at 64 pairs) instead of the 25200-row prediction tensor
     (51.6 MB) - SURVEY.md section 8f rank 1.  ``nms(pred) -> (dets, counts)`` is
     ``utils.general.batched_nms`` (or a partial of it).  Returns (dets [B, max_det, 6], counts [B]) on all ranks."""
-    pred, _ = model(shard_batch(rgb, rank, world), shard_batch(ir, rank, world))
+    a, b = shard_batch(rgb, rank, world), shard_batch(ir, rank, world)
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    if a.shape[0] == 0 and multi:
+        dets = all_gather_detections(None, world, group, like=(3, torch.float32, rgb.device))
+        counts = all_gather_detections(None, world, group, like=(2, torch.float32, rgb.device))
+        return dets, counts.view(-1).to(torch.int32)
+    pred, _ = model(a, b)
     dets, counts = nms(pred)
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not multi:
         return dets, counts
     return all_gather_detections(dets, world, group), all_gather_detections(counts.view(-1, 1).to(torch.float32), world, group).view(-1).to(counts.dtype)
+
+
+def timed_steps(step_fn, steps, warmup, world=1, gather=None, sync=None, group=None):
+    """The measurement loop of bench.py, factored out so that its N > 1 control flow runs under the CPU (gloo)
+    tests too: ``warmup`` untimed steps, then EXACTLY ``steps`` timed steps bracketed by barrier + device sync on
+    both sides; returns the MAX elapsed seconds over ranks.  ``step_fn()`` runs one step and returns the tensor to
+    gather (or None); ``gather`` is an ``OverlappedGather`` (its collective of step i overlaps step i+1 and all of
+    them are drained inside the timed region); ``sync`` is ``torch.cuda.synchronize`` on a GPU, a no-op on CPU."""
+    sync = sync or (lambda: None)
+    multi = world > 1 and dist.is_initialized()
+
+    def one():
+        out = step_fn()
+        if gather is not None and out is not None:
+            gather.submit(out)
+
+    for _ in range(warmup):
+        one()
+    if gather is not None:
+        gather.drain()
+    if multi:
+        dist.barrier(group=group)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    if gather is not None:
+        gather.drain()                      # every gather of the K timed steps has completed
+    sync()
+    if multi:
+        dist.barrier(group=group)
+    elapsed = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gather.out[0].device if gather is not None else "cpu")
+        if t.device.type == "cpu" and dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        elapsed = float(t.item())
+    return elapsed
 
 
 class OverlappedGather:

@@ -148,6 +148,18 @@ def set_launch_log(log):
     _launch_log = log
 
 
+def _timed(name, flops, abytes, fn):
+    """Run ``fn()`` (one kernel launch); when a launch log is installed bracket it with HIP events."""
+    if _launch_log is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    st = fn()
+    e1.record()
+    _launch_log.append((name, flops, e0, e1, abytes))
+    return st
+
+
 def _timed_gemm(lib, rows, pk, args, abytes=0.0, kind="conv"):
     if _launch_log is None:
         return lib.cft_conv2d(*args)
@@ -369,8 +381,10 @@ def gpt_tokenize(rgb, ir, pos_emb):
     ir, ld_i = as_nhwc(ir)
     B, C, H, W = rgb.shape
     tokens = torch.empty((B, 128, C), dtype=torch.float32, device=rgb.device)
-    st = _lib.load().cft_gpt_tokenize(rgb.data_ptr(), ld_r, 0, ir.data_ptr(), ld_i, 0, pos_emb.data_ptr(), tokens.data_ptr(),
-                                      B, H, W, C, _dt(rgb.dtype), _stream())
+    lib = _lib.load()
+    st = _timed("cft_tokenize", 0.0, 2.0 * B * H * W * C * rgb.element_size() + B * 128 * C * 4,
+                lambda: lib.cft_gpt_tokenize(rgb.data_ptr(), ld_r, 0, ir.data_ptr(), ld_i, 0, pos_emb.data_ptr(), tokens.data_ptr(),
+                                             B, H, W, C, _dt(rgb.dtype), _stream()))
     _lib.check(st, "cft_gpt_tokenize")
     return tokens
 
@@ -380,7 +394,9 @@ def layernorm(x, gamma, beta, out_dtype, eps=1e-5):
     _require_cuda(x, "layernorm")
     rows, C = x.shape
     out = torch.empty((rows, C), dtype=out_dtype, device=x.device)
-    st = _lib.load().cft_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), rows, C, eps, _dt(out_dtype), _stream())
+    lib = _lib.load()
+    st = _timed("cft_layernorm", 0.0, rows * C * (4.0 + out.element_size()),
+                lambda: lib.cft_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), rows, C, eps, _dt(out_dtype), _stream()))
     _lib.check(st, "cft_layernorm")
     return out
 
@@ -388,7 +404,9 @@ def layernorm(x, gamma, beta, out_dtype, eps=1e-5):
 def attention(qkv, B, heads, dk, dkp):
     _require_cuda(qkv, "attention")
     out = torch.empty((B * 128, heads * dkp), dtype=qkv.dtype, device=qkv.device)
-    st = _lib.load().cft_attention(qkv.data_ptr(), out.data_ptr(), B, heads, dk, dkp, _dt(qkv.dtype), _stream())
+    lib = _lib.load()
+    st = _timed("cft_attention", 4.0 * 128 * 128 * dk * heads * B, 4.0 * B * 128 * heads * dkp * qkv.element_size(),
+                lambda: lib.cft_attention(qkv.data_ptr(), out.data_ptr(), B, heads, dk, dkp, _dt(qkv.dtype), _stream()))
     _lib.check(st, "cft_attention")
     return out
 
@@ -404,7 +422,9 @@ def gpt_upsample_add(tokens, s, base, H, W, dtype):
         if tuple(base.shape) != (B, C, H, W) or base.dtype != dtype:
             raise ValueError("gpt_upsample_add: base shape/dtype mismatch")
         bp = base.data_ptr()
-    st = _lib.load().cft_gpt_upsample_add(tokens.data_ptr(), s, bp, ldb, 0, out.data_ptr(), C, 0, B, H, W, C, _dt(dtype), _stream())
+    lib = _lib.load()
+    st = _timed("cft_upsample_add", 0.0, (2.0 if bp else 1.0) * B * H * W * C * out.element_size(),
+                lambda: lib.cft_gpt_upsample_add(tokens.data_ptr(), s, bp, ldb, 0, out.data_ptr(), C, 0, B, H, W, C, _dt(dtype), _stream()))
     _lib.check(st, "cft_gpt_upsample_add")
     return out
 

@@ -8,22 +8,25 @@ from .. import _lib
 from ..ops import _require_cuda, _stream
 
 MAX_WH = 4096  # class offset in pixels (reference utils/general.py:467)
+MAX_NMS = 30000  # boxes that enter the suppression at most (reference utils/general.py:469)
 
 
-def _class_mask(classes):
+def _class_table(classes, nc, device):
+    """uint8 [nc] allow-table for the kernel (exact for any class id, reference :505-506), None = all classes."""
     if classes is None:
-        return (1 << 64) - 1
-    m = 0
+        return None
+    t = torch.zeros((nc,), dtype=torch.uint8)
     for c in classes:
-        if int(c) < 64:
-            m |= 1 << int(c)
-    return m
+        if 0 <= int(c) < nc:
+            t[int(c)] = 1
+    return t.to(device)
 
 
-def batched_nms(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300):
+def batched_nms(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300,
+                max_nms=MAX_NMS):
     """prediction [B, rows, nc+5] (fp32, on the GPU) -> (dets [B, max_det, 6] = (x1,y1,x2,y2,conf,cls),
-    counts [B] int32).  No host synchronisation: fit for HIP-graph capture and for all-gathering the
-    <= max_det survivors instead of all rows."""
+    counts [B] int32).  No host synchronisation (unless ``classes`` is given as a Python list: one small H2D copy):
+    fit for HIP-graph capture and for all-gathering the <= max_det survivors instead of all rows."""
     _require_cuda(prediction, "batched_nms")
     if prediction.dtype != torch.float32 or not prediction.is_contiguous():
         prediction = prediction.float().contiguous()
@@ -34,9 +37,10 @@ def batched_nms(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnos
     scratch = torch.empty((B * cap * 32,), dtype=torch.uint8, device=prediction.device)
     dets = torch.zeros((B, max_det, 6), dtype=torch.float32, device=prediction.device)
     counts = torch.zeros((B,), dtype=torch.int32, device=prediction.device)
+    allow = classes if isinstance(classes, torch.Tensor) and classes.dtype == torch.uint8 else _class_table(classes, nc, prediction.device)
     st = _lib.load().cft_nms(prediction.data_ptr(), B, rows, no, float(conf_thres), float(iou_thres), int(bool(agnostic)),
-                             int(multi_label), _class_mask(classes), int(max_det), scratch.data_ptr(), scratch.numel(),
-                             dets.data_ptr(), counts.data_ptr(), _stream())
+                             int(multi_label), allow.data_ptr() if allow is not None else None, int(max_det), int(max_nms),
+                             scratch.data_ptr(), scratch.numel(), dets.data_ptr(), counts.data_ptr(), _stream())
     _lib.check(st, "cft_nms")
     return dets, counts
 
@@ -45,8 +49,19 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
                         labels=()):
     """Same signature and return value as the reference: a list with one (n,6) tensor [xyxy, conf, cls] per
     image, sorted by descending confidence, n <= 300."""
-    if labels:
-        raise NotImplementedError("autolabelling a-priori labels (reference :480-487) are not supported")
+    if labels and any(len(l) for l in labels):
+        # autolabelling (reference :480-487): a-priori labels [cls, x, y, w, h] join the image's candidates as rows
+        # with obj = 1 and a one-hot class; images with fewer labels get obj = 0 padding rows (filtered in phase 1)
+        B, rows, no = prediction.shape
+        L = max(len(l) for l in labels)
+        extra = torch.zeros((B, L, no), dtype=torch.float32, device=prediction.device)
+        for xi, l in enumerate(labels):
+            if len(l):
+                l = torch.as_tensor(l, dtype=torch.float32, device=prediction.device)
+                extra[xi, :len(l), :4] = l[:, 1:5]
+                extra[xi, :len(l), 4] = 1.0
+                extra[xi, torch.arange(len(l), device=prediction.device), l[:, 0].long() + 5] = 1.0
+        prediction = torch.cat((prediction.float(), extra), 1)
     dets, counts = batched_nms(prediction, conf_thres, iou_thres, classes, agnostic, multi_label)
     counts = counts.tolist()
     return [dets[i, :n] for i, n in enumerate(counts)]

@@ -1,0 +1,143 @@
+"""Storage-precision model of the 16-bit HIP path, on the CPU.
+
+TEST INFRASTRUCTURE ONLY (same rules as ``cft_oracle.py``: imported by ``tests/`` only, never by
+the product package).
+
+The 16-bit kernels multiply 16-bit operands exactly, accumulate in fp32 and round ONCE per stored
+tensor.  Their deviation from the fp32 reference forward is therefore - to first order - the sum
+of those storage roundings.  ``LowpOracle`` evaluates the reference algorithm (the functions of
+``cft_oracle.py``, i.e. reference models/common.py:36-50, 99-109, 131-143, 154-179, 211-243,
+430-639 and models/yolo_test.py:25-64) in fp32 and applies ``x.to(dtype).float()`` at exactly the
+points where the product stores a 16-bit tensor:
+
+* folded conv / linear weights (BN folded in fp32 first, utils/torch_utils.py:181-201);
+* every Conv / C3 / SPP / Focus output (after bias + SiLU + residual add), Add / Add2 outputs;
+* in the CFT block: LayerNorm outputs, q/k/v, the exponentials P, the attention output and the
+  GELU hidden layer; the token residual stream, ln_f and the Detect logits stay fp32.
+
+It answers two questions the fp32 oracle cannot:
+  1. is the HIP 16-bit result what its storage precision predicts (tight bound, same roundings), and
+  2. how far can ANY implementation with 16-bit storage of that type be from the fp32 reference
+     (bf16: 1.2-1.5e-2 in sigmoid space on the lively seeded weights; fp16: 1.3-1.6e-3).
+"""
+import torch
+import torch.nn.functional as F
+
+from .cft_oracle import BN_EPS, LN_EPS, build_graph, detect, sorted_anchors
+
+def _forward(cfg, sd, rgb, ir, q, res32=False):
+
+    def conv(p, x, k, s, act=True, res=None, rnd=True):
+        w = sd[p + "conv.weight"]
+        if p + "bn.weight" in sd:
+            scale = sd[p + "bn.weight"] / torch.sqrt(sd[p + "bn.running_var"] + BN_EPS)
+            w = w * scale.view(-1, 1, 1, 1)
+            b = sd[p + "bn.bias"] - sd[p + "bn.running_mean"] * scale
+        else:
+            b = sd[p + "conv.bias"]
+        y = F.conv2d(x, q(w), b, s, k // 2)
+        y = F.silu(y) if act else y
+        if res is not None:
+            y = y + res
+        return q(y) if rnd else y
+
+    def c3(p, x, n, shortcut):
+        a = conv(p + "cv1.", x, 1, 1)
+        b = conv(p + "cv2.", x, 1, 1)
+        a32 = a
+        for j in range(n):
+            t = conv(f"{p}m.{j}.cv1.", a, 1, 1)
+            if res32 and shortcut:
+                a32 = conv(f"{p}m.{j}.cv2.", t, 3, 1, res=a32, rnd=False)
+                a = q(a32)
+            else:
+                a = conv(f"{p}m.{j}.cv2.", t, 3, 1, res=a if shortcut else None)
+        return conv(p + "cv3.", torch.cat((a, b), 1), 1, 1)
+
+    def lin(x, w, b):
+        return F.linear(x, q(w), b)
+
+    def gpt(p, r, t_):
+        b, c, H, W = r.shape
+        h, A = 8, 8
+        rr = F.adaptive_avg_pool2d(r, (A, A)).reshape(b, c, -1)
+        tt = F.adaptive_avg_pool2d(t_, (A, A)).reshape(b, c, -1)
+        x = torch.cat([rr, tt], 2).permute(0, 2, 1) + sd[p + "pos_emb"]
+        l = 0
+        while f"{p}trans_blocks.{l}.ln_input.weight" in sd:
+            bp = f"{p}trans_blocks.{l}."
+            y = q(F.layer_norm(x, (c,), sd[bp + "ln_input.weight"], sd[bp + "ln_input.bias"], LN_EPS))
+            dk = c // h
+            sp = bp + "sa."
+            qq = q(lin(y, sd[sp + "que_proj.weight"], sd[sp + "que_proj.bias"])).view(b, 128, h, dk).permute(0, 2, 1, 3)
+            kk = q(lin(y, sd[sp + "key_proj.weight"], sd[sp + "key_proj.bias"])).view(b, 128, h, dk).permute(0, 2, 3, 1)
+            vv = q(lin(y, sd[sp + "val_proj.weight"], sd[sp + "val_proj.bias"])).view(b, 128, h, dk).permute(0, 2, 1, 3)
+            s = torch.matmul(qq, kk) / dk ** 0.5
+            pe = torch.exp(s - s.max(-1, keepdim=True)[0])
+            o = torch.matmul(q(pe), vv) / pe.sum(-1, keepdim=True)   # the row sum is taken before the rounding of P
+            o = q(o.permute(0, 2, 1, 3).reshape(b, 128, c))
+            x = x + lin(o, sd[sp + "out_proj.weight"], sd[sp + "out_proj.bias"])
+            y = q(F.layer_norm(x, (c,), sd[bp + "ln_output.weight"], sd[bp + "ln_output.bias"], LN_EPS))
+            hid = q(F.gelu(lin(y, sd[bp + "mlp.0.weight"], sd[bp + "mlp.0.bias"])))
+            x = x + lin(hid, sd[bp + "mlp.2.weight"], sd[bp + "mlp.2.bias"])
+            l += 1
+        x = F.layer_norm(x, (c,), sd[p + "ln_f.weight"], sd[p + "ln_f.bias"], LN_EPS)
+        x = x.view(b, 2, A, A, c).permute(0, 1, 4, 2, 3)
+        return (F.interpolate(x[:, 0].contiguous(), size=(H, W), mode="bilinear"),
+                F.interpolate(x[:, 1].contiguous(), size=(H, W), mode="bilinear"))
+
+    layers, save = build_graph(cfg)
+    y = []
+    x = rgb
+    for L in layers:
+        i, f, t = L["i"], L["f"], L["type"]
+        p = f"model.{i}."
+        if f == -4:
+            xin = ir
+        elif f == -1:
+            xin = x
+        elif isinstance(f, int):
+            xin = y[f]
+        else:
+            xin = [x if j == -1 else y[j] for j in f]
+        if t == "Conv":
+            x = conv(p, xin, L["k"], L["s"])
+        elif t == "Focus":
+            z = torch.cat([xin[..., ::2, ::2], xin[..., 1::2, ::2], xin[..., ::2, 1::2], xin[..., 1::2, 1::2]], 1)
+            x = conv(p + "conv.", q(z), L["k"], L["s"])
+        elif t == "C3":
+            x = c3(p, xin, L["n"], L["shortcut"])
+        elif t == "SPP":
+            a = conv(p + "cv1.", xin, 1, 1)
+            x = conv(p + "cv2.", torch.cat([a] + [F.max_pool2d(a, k, 1, k // 2) for k in L["k"]], 1), 1, 1)
+        elif t == "Concat":
+            x = torch.cat(xin, 1)
+        elif t == "Add":
+            x = q(xin[0] + xin[1])
+        elif t == "Add2":
+            x = q(xin[0] + xin[1][L["index"]])
+        elif t == "GPT":
+            x = gpt(p, xin[0], xin[1])
+        elif t == "nn.Upsample":
+            x = F.interpolate(xin, scale_factor=float(L["scale"]), mode=L["mode"])
+        elif t == "Detect":
+            sdq = dict(sd)
+            for j in range(len(xin)):
+                sdq[f"{p}m.{j}.weight"] = q(sd[f"{p}m.{j}.weight"])
+            ag = sd[p + "anchor_grid"] if p + "anchor_grid" in sd else sorted_anchors(L["anchors"])[1]
+            x = detect(sdq, p, list(xin), L["nc"], ag)
+        y.append(x if i in save else None)
+    return x
+
+
+class LowpOracle:
+    """``LowpOracle(cfg, torch.bfloat16 | torch.float16)(state_dict, rgb, ir) -> (pred, [raw]*3)``."""
+
+    def __init__(self, cfg, dtype, res32=False):
+        self.cfg, self.dtype, self.res32 = cfg, dtype, res32
+
+    @torch.no_grad()
+    def __call__(self, sd, rgb, ir):
+        sd = {k: v.float() if v.is_floating_point() else v for k, v in sd.items()}
+        dt = self.dtype
+        return _forward(self.cfg, sd, rgb.float(), ir.float(), lambda x: x.to(dt).float(), self.res32)

@@ -37,15 +37,24 @@ def greedy_nms(boxes, scores, iou_threshold):
     return torch.tensor(keep, dtype=torch.long)
 
 
-def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False):
-    """reference utils/general.py:455-543 (labels / merge-NMS branches, both off by default, omitted)."""
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                        labels=(), max_nms=30000):
+    """reference utils/general.py:455-543 (merge-NMS branch, off in the reference, omitted).  ``max_nms`` is the
+    reference's constant (:469), a parameter here only so that tests can reach the truncation with small inputs."""
     nc = prediction.shape[2] - 5
     xc = prediction[..., 4] > conf_thres
-    max_wh, max_det, max_nms = 4096, 300, 30000
+    max_wh, max_det = 4096, 300
     multi_label = multi_label and nc > 1
     output = [torch.zeros((0, 6))] * prediction.shape[0]
     for xi, x in enumerate(prediction):
         x = x[xc[xi]].clone()
+        if labels and len(labels[xi]):       # :480-487
+            l = torch.as_tensor(labels[xi], dtype=torch.float32)
+            v = torch.zeros((len(l), nc + 5))
+            v[:, :4] = l[:, 1:5]
+            v[:, 4] = 1.0
+            v[range(len(l)), l[:, 0].long() + 5] = 1.0
+            x = torch.cat((x, v), 0)
         if not x.shape[0]:
             continue
         x[:, 5:] *= x[:, 4:5]
@@ -62,7 +71,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         if not n:
             continue
         if n > max_nms:
-            x = x[x[:, 4].argsort(descending=True)[:max_nms]]
+            x = x[x[:, 4].argsort(descending=True, stable=True)[:max_nms]]
         c = x[:, 5:6] * (0 if agnostic else max_wh)
         i = greedy_nms(x[:, :4] + c, x[:, 4], iou_thres)[:max_det]
         output[xi] = x[i]

@@ -112,9 +112,46 @@ def make_nms_golden():
     torch.save(cases, os.path.join(HERE, "nms_cases.pt"))
 
 
+def make_checkpoint():
+    """A checkpoint exactly as the reference's train.py:850-860 writes one - the whole ``nn.Module`` pickled,
+    ``.half()``, inside a dict with ``ema`` - for a deliberately tiny two-stream CFTx3 network (width 0.0625:
+    8..64 channels, GPT widths 16/32/64, i.e. head widths 2/4/8 that the attention kernel zero-pads).
+    ``ref_ckpt_tiny.pt`` holds nothing but what the reference's own classes pickle; ``ref_ckpt_tiny_out.pt`` holds
+    the reference's outputs for it (after ``attempt_load``'s ``.float().fuse().eval()``,
+    models/experimental.py:119) on seeded inputs.  The GPU box has no /root/reference: the -m gpu test
+    un-pickles this file through ``compat.attempt_load``."""
+    install_reference()
+    sys.path.insert(0, ROOT)
+    import copy
+    import msod_amd  # noqa: F401
+    from msod_amd.models.configs import named_config
+    from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict
+    from models.yolo_test import Model  # the reference
+    cfg = copy.deepcopy(named_config("yolov5s_fusion_transformerx3_vedai"))
+    cfg["width_multiple"], cfg["nc"] = 0.0625, 3
+    torch.manual_seed(0)
+    model = Model(cfg).eval()
+    model.load_state_dict(seeded_state_dict(model.state_dict(), 9))
+    model.names = ["person", "car", "bicycle"]
+    ck = {"epoch": 7, "best_fitness": 0.5, "training_results": None, "model": copy.deepcopy(model).half(),
+          "ema": None, "optimizer": None, "wandb_id": None}
+    path = os.path.join(HERE, "ref_ckpt_tiny.pt")
+    torch.save(ck, path)
+    loaded = torch.load(path, map_location="cpu", weights_only=False)["model"].float().fuse().eval()
+    rgb, ir = seeded_inputs(2, 96, 128, 9)
+    with torch.no_grad():
+        pred, raw = loaded(rgb, ir)
+    torch.save({"cfg": cfg, "seed": 9, "batch": 2, "height": 96, "width": 128, "pred": pred.clone(), "raw": [r.clone() for r in raw],
+                "names": loaded.names, "stride": loaded.stride.clone()}, os.path.join(HERE, "ref_ckpt_tiny_out.pt"))
+    print(f"ref_ckpt_tiny.pt {os.path.getsize(path)/1e3:.0f} kB, pred {tuple(pred.shape)}, raw std {raw[0].std():.3f}")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "nms":
         make_nms_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ckpt":
+        make_checkpoint()
     else:
         main()
         make_nms_golden()
+        make_checkpoint()

@@ -1,6 +1,6 @@
 """One-shot GPU diagnostics (not a pytest file): end-to-end error of the HIP model against the CPU
-oracle for several configs and both precisions, plus the error the REFERENCE ALGORITHM itself shows
-when evaluated in bf16 (CPU autocast of the oracle) for context.  Writes gpurun_out/diag.json."""
+oracle for several configs and the three precisions, plus what 16-bit STORAGE alone costs on the same network
+(oracle/lowp_oracle.py) and how close the HIP 16-bit result is to that storage model.  Writes gpurun_out/diag.json."""
 import json
 import os
 import sys
@@ -15,6 +15,7 @@ from msod_amd.models.configs import named_config  # noqa: E402
 from msod_amd.models.yolo_test import Model  # noqa: E402
 from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict  # noqa: E402
 from oracle.cft_oracle import OracleModel  # noqa: E402
+from oracle.lowp_oracle import LowpOracle  # noqa: E402
 
 
 def metrics(pred, raw, wpred, wraw):
@@ -36,7 +37,7 @@ def metrics(pred, raw, wpred, wraw):
 def main():
     out = []
     cases = [("cfg1", 1, 320, 320), ("cfg2", 2, 256, 256), ("yolov5s_fusion_transformerx3_vedai", 2, 192, 320),
-             ("yolov5s_fusion_transformer_vedai", 1, 256, 256), ("cfg3", 1, 256, 256)]
+             ("yolov5s_fusion_transformer_vedai", 1, 256, 256), ("cfg3", 1, 256, 256), ("cfg3", 1, 640, 640), ("cfg5", 1, 640, 640)]
     for name, b, h, w in cases:
         cfg = named_config(name)
         model = Model(cfg)
@@ -46,18 +47,22 @@ def main():
         t0 = time.time()
         wpred, wraw = OracleModel(cfg)(sd, rgb, ir)
         t_or = time.time() - t0
-        with torch.autocast("cpu", dtype=torch.bfloat16):
-            apred, araw = OracleModel(cfg)(sd, rgb, ir)
-        rec = {"case": name, "shape": [b, h, w], "oracle_s": t_or,
-               "reference_algorithm_bf16_autocast": metrics(apred, araw, wpred, wraw)}
+        rec = {"case": name, "shape": [b, h, w], "oracle_s": t_or}
+        lowp = {}
+        for dt in (torch.bfloat16, torch.float16):      # what 16-bit STORAGE alone costs (oracle/lowp_oracle.py)
+            lp, lr = LowpOracle(cfg, dt)(sd, rgb, ir)
+            lowp[dt] = (lp, lr)
+            rec[f"storage_model_{dt}_vs_fp32"] = metrics(lp, lr, wpred, wraw)
         model = model.cuda()
-        for dtype in (torch.float32, torch.bfloat16):
+        for dtype in (torch.float32, torch.float16, torch.bfloat16):
             model.set_compute_dtype(dtype)
             try:
                 with torch.no_grad():
                     pred, raw = model(rgb.cuda(), ir.cuda())
                 torch.cuda.synchronize()
                 rec[str(dtype)] = metrics(pred, raw, wpred, wraw)
+                if dtype in lowp:
+                    rec[f"{dtype}_vs_storage_model"] = metrics(pred, raw, *lowp[dtype])
             except Exception as e:  # keep going: one report per run
                 rec[str(dtype)] = {"error": repr(e)}
         print(json.dumps(rec), flush=True)

@@ -50,6 +50,26 @@ def _worker(rank, world, port, n_pairs, q):
     ok = ok and torch.equal(outs[3][1], torch.cat([torch.full((2, 3), 30.0 + r) for r in range(world)]))
     same = D.gather_equal(torch.full((2, 3, 4), float(rank)))
     ok = ok and torch.equal(same, torch.cat([torch.full((2, 3, 4), 0.0), torch.full((2, 3, 4), 1.0)]))
+    # bench.py's measurement loop (timed_steps) with a stub step: rank 1 is the slow rank, both ranks must report ITS time;
+    # the overlapped gather must have delivered the last timed step's tensor from both ranks
+    import time
+    calls = []
+    static = torch.zeros(2, 3)
+
+    def step_fn():
+        calls.append(len(calls))
+        time.sleep(0.02 if rank == 1 else 0.002)
+        static.fill_(100.0 * len(calls) + rank)
+        return static
+
+    og2 = D.OverlappedGather(static, world)
+    elapsed = D.timed_steps(step_fn, steps=4, warmup=2, world=world, gather=og2)
+    ok = ok and len(calls) == 6 and elapsed >= 4 * 0.02 * 0.9
+    ok = ok and torch.equal(og2.drain(), torch.cat([torch.full((2, 3), 600.0 + r) for r in range(world)]))
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    both = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(both, t)
+    ok = ok and float(both[0]) == float(both[1])           # MAX over ranks: identical on every rank
     q.put((rank, ok, tuple(out.shape)))
     dist.barrier()
     dist.destroy_process_group()
@@ -82,3 +102,8 @@ def test_two_rank_equal_shards():
 
 def test_two_rank_ragged_shards():
     _run(5)
+
+
+def test_two_rank_one_empty_shard():
+    """Global batch 1 on 2 ranks: rank 1 has no pair, skips the forward and still joins the collectives."""
+    _run(1)

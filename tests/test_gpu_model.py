@@ -1,11 +1,20 @@
 """End-to-end parity of the HIP model against the CPU oracle (same seeded weights and inputs) and
-the committed golden vectors, plus size-independent properties at the full BASELINE shape.
+the committed golden vectors, at the golden shapes AND at the BASELINE shapes, plus size-independent
+properties.
 
-Tolerances (BASELINE.json north_star: 1e-3 fp32 / 1e-2 bf16; SURVEY.md D8 explains why the
-pixel-space columns need a relative bound):
-  fp32  raw head logits  |err| <= 1e-3 absolute;   decoded pred  allclose(rtol=1e-3, atol=1e-3)
-  bf16  see BF16_* below - measured against what the reference algorithm itself loses when it
-        is evaluated in bf16 (CPU autocast), recorded in gpurun_out/diag.json by tests/gpu_diag.py.
+Tolerances (BASELINE.json north_star: 1e-3 fp32 / 1e-2 for the 16-bit path; SURVEY.md D8: an absolute
+bound is only meaningful in sigmoid space, pixel-space columns get a relative one):
+
+  fp32   raw head logits |err| <= 1e-3 absolute; decoded pred allclose(rtol=1e-3, atol=1e-3) - vs the oracle
+         AND vs the reference's own outputs (tests/golden/*.pt)
+  fp16   sigmoid-space max-abs (conf/cls and sigma(box logits)) <= 1e-2 vs the fp32 oracle.  fp16 is the
+         precision the reference itself runs on a GPU (test.py:66-68 `model.half()`).
+  bf16   (a) the HIP result is what bf16 STORAGE predicts: sigmoid-space max-abs <= BF16_VS_LOWP against
+         oracle/lowp_oracle.py (fp32 oracle + a bf16 rounding wherever the product stores a bf16 tensor);
+         (b) vs the fp32 oracle <= BF16_SIGMOID_ATOL = 2.5e-2.  bf16 keeps 8 significand bits; ~100 stored
+         layers deep, ANY implementation with bf16 storage is 1.0-1.5e-2 away from fp32 on these
+         deliberately lively weights (oracle/lowp_oracle.py, tests/precision_study.py), so 1e-2 is not
+         attainable in bf16 and (a) is the meaningful check for it.
 """
 import glob
 import os
@@ -16,11 +25,16 @@ import torch
 from test_oracle_golden import load_case
 
 pytestmark = pytest.mark.gpu
-GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.pt")) if not os.path.basename(p).startswith("nms_"))
-SMALL = [p for p in GOLDEN if "/l_" not in p] + [p for p in GOLDEN if "l_x3_llvip" in p]
+HERE = os.path.dirname(__file__)
+GOLDEN = sorted(p for p in glob.glob(os.path.join(HERE, "golden", "*.pt"))
+                if not os.path.basename(p).startswith(("nms_", "ref_ckpt")))
+IDS = [os.path.basename(p)[:-3] for p in GOLDEN]
 
-BF16_SIGMOID_ATOL = 4e-2    # conf/cls probabilities and sigmoid of box logits
-BF16_LOGIT_RMS = 3e-2       # rms error of the raw logits relative to their std
+F16_SIGMOID_ATOL = 1e-2     # north_star's 16-bit bound, met in fp16 (measured <= 2e-3)
+F16_LOGIT_RMS = 5e-3
+BF16_SIGMOID_ATOL = 2.5e-2  # bf16 storage floor is 1.0-1.5e-2 on these weights (see module docstring)
+BF16_LOGIT_RMS = 3e-2
+BF16_VS_LOWP = 6e-3         # HIP bf16 vs the bf16-storage model of the oracle: same roundings, fp32 accumulation order differs
 
 
 def _run(model, rgb, ir, dev, dtype):
@@ -31,32 +45,136 @@ def _run(model, rgb, ir, dev, dtype):
     return pred.cpu(), [r.cpu() for r in raw]
 
 
-@pytest.mark.parametrize("path", SMALL, ids=[os.path.basename(p)[:-3] for p in SMALL])
+def _flat(raws):
+    return torch.cat([r.reshape(-1) for r in raws])
+
+
+def _sig_err(raw, want_raw):
+    return (_flat(raw).sigmoid() - _flat(want_raw).sigmoid()).abs().max().item()
+
+
+def _rms_rel(raw, want_raw):
+    a, b = _flat(raw), _flat(want_raw)
+    return ((a - b).pow(2).mean().sqrt() / b.std()).item()
+
+
+def _check_fp32(pred, raw, want_pred, want_raw):
+    for a, b in zip(raw, want_raw):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= 1e-3
+    assert torch.allclose(pred, want_pred, rtol=1e-3, atol=1e-3)
+
+
+def _check_f16(pred, raw, want_pred, want_raw):
+    assert _sig_err(raw, want_raw) <= F16_SIGMOID_ATOL
+    assert _rms_rel(raw, want_raw) <= F16_LOGIT_RMS
+    assert (pred[..., 4:] - want_pred[..., 4:]).abs().max().item() <= F16_SIGMOID_ATOL
+    assert torch.allclose(pred[..., :4], want_pred[..., :4], rtol=2e-2, atol=1.0)   # pixel columns: relative + 1 px
+
+
+def _check_bf16(pred, raw, want_pred, want_raw, lowp_raw=None):
+    assert _sig_err(raw, want_raw) <= BF16_SIGMOID_ATOL
+    assert _rms_rel(raw, want_raw) <= BF16_LOGIT_RMS
+    assert (pred[..., 4:] - want_pred[..., 4:]).abs().max().item() <= BF16_SIGMOID_ATOL
+    if lowp_raw is not None:
+        assert _sig_err(raw, lowp_raw) <= BF16_VS_LOWP
+
+
+# ------------------------------------------------------------------------- golden shapes, every config
+@pytest.mark.parametrize("path", GOLDEN, ids=IDS)
 def test_fp32_matches_oracle_and_golden(dev, path):
     from oracle.cft_oracle import OracleModel
     g, cfg, model, rgb, ir = load_case(path)
     want_pred, want_raw = OracleModel(cfg)(model.state_dict(), rgb, ir)
     pred, raw = _run(model, rgb, ir, dev, torch.float32)
-    for a, b, c in zip(raw, want_raw, g["raw"]):
-        assert a.shape == b.shape
-        assert (a - b).abs().max().item() <= 1e-3
-        assert (a - c).abs().max().item() <= 1e-3          # and against the reference's own output
-    assert torch.allclose(pred, want_pred, rtol=1e-3, atol=1e-3)
-    assert torch.allclose(pred, g["pred"], rtol=1e-3, atol=1e-3)
+    _check_fp32(pred, raw, want_pred, want_raw)
+    _check_fp32(pred, raw, g["pred"], g["raw"])            # and against the reference's own output
 
 
-@pytest.mark.parametrize("path", SMALL, ids=[os.path.basename(p)[:-3] for p in SMALL])
-def test_bf16_matches_oracle(dev, path):
+@pytest.mark.parametrize("path", GOLDEN, ids=IDS)
+def test_f16_matches_oracle_within_1e2(dev, path):
     from oracle.cft_oracle import OracleModel
     g, cfg, model, rgb, ir = load_case(path)
     want_pred, want_raw = OracleModel(cfg)(model.state_dict(), rgb, ir)
+    pred, raw = _run(model, rgb, ir, dev, torch.float16)
+    _check_f16(pred, raw, want_pred, want_raw)
+    _check_f16(pred, raw, g["pred"], g["raw"])
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=IDS)
+def test_bf16_matches_its_storage_model_and_oracle(dev, path):
+    from oracle.cft_oracle import OracleModel
+    from oracle.lowp_oracle import LowpOracle
+    g, cfg, model, rgb, ir = load_case(path)
+    sd = model.state_dict()
+    want_pred, want_raw = OracleModel(cfg)(sd, rgb, ir)
+    _, lowp_raw = LowpOracle(cfg, torch.bfloat16)(sd, rgb, ir)
     pred, raw = _run(model, rgb, ir, dev, torch.bfloat16)
-    a = torch.cat([r.reshape(-1) for r in raw]); b = torch.cat([r.reshape(-1) for r in want_raw])
-    assert ((a - b).pow(2).mean().sqrt() / b.std()).item() <= BF16_LOGIT_RMS
-    assert (a.sigmoid() - b.sigmoid()).abs().max().item() <= BF16_SIGMOID_ATOL
-    assert (pred[..., 4:] - want_pred[..., 4:]).abs().max().item() <= BF16_SIGMOID_ATOL
+    _check_bf16(pred, raw, want_pred, want_raw, lowp_raw)
 
 
+# ------------------------------------------------------------------------- BASELINE shapes
+def _seeded(cfg_name, seed):
+    from msod_amd.models.configs import named_config
+    from msod_amd.models.yolo_test import Model
+    from msod_amd.utils.seeded import seeded_state_dict
+    cfg = named_config(cfg_name)
+    model = Model(cfg)
+    sd = seeded_state_dict(model.state_dict(), seed)
+    model.load_state_dict(sd)
+    return cfg, model, sd
+
+
+def test_cfg2_full_shape_fp32_tolerance_check(dev):
+    """BASELINE config 2 as specified: yolov5s + 1 CFT block, 640x640, batch 16, fp32, every pair vs the oracle."""
+    from msod_amd.utils.seeded import seeded_inputs
+    from oracle.cft_oracle import OracleModel
+    cfg, model, sd = _seeded("cfg2", 42)
+    rgb, ir = seeded_inputs(16, 640, 640, 42)
+    want_pred, want_raw = OracleModel(cfg)(sd, rgb, ir)
+    pred, raw = _run(model.fuse(), rgb, ir, dev, torch.float32)
+    assert pred.shape == (16, 25200, 14)
+    _check_fp32(pred, raw, want_pred, want_raw)
+
+
+def test_cfg3_full_shape_all_precisions(dev):
+    """BASELINE config 3 network at its own shape (yolov5l + CFTx3 FLIR, 640x640): two pairs, fp32 / fp16 / bf16
+    vs the oracle; the 16-bit runs use the deployed form (BN folded) like bench.py."""
+    from msod_amd.utils.seeded import seeded_inputs
+    from oracle.cft_oracle import OracleModel
+    from oracle.lowp_oracle import LowpOracle
+    cfg, model, sd = _seeded("cfg3", 0)
+    rgb, ir = seeded_inputs(2, 640, 640, 0)
+    want_pred, want_raw = OracleModel(cfg)(sd, rgb, ir)
+    model.fuse()
+    pred, raw = _run(model, rgb, ir, dev, torch.float32)
+    assert pred.shape == (2, 25200, 8)
+    _check_fp32(pred, raw, want_pred, want_raw)
+    pred, raw = _run(model, rgb, ir, dev, torch.float16)
+    _check_f16(pred, raw, want_pred, want_raw)
+    _, lowp_raw = LowpOracle(cfg, torch.bfloat16)(sd, rgb[:1], ir[:1])
+    pred, raw = _run(model, rgb, ir, dev, torch.bfloat16)
+    _check_bf16(pred, raw, want_pred, want_raw)
+    assert _sig_err([r[:1] for r in raw], lowp_raw) <= BF16_VS_LOWP
+
+
+def test_cfg5_one_pair_at_1280(dev):
+    """BASELINE config 5 network (yolov5x x3 CFT, 80/160/320/640/1280 channels, head widths 40/80/160) at
+    1280x1280, one pair: fp32 and fp16 vs the oracle."""
+    from msod_amd.utils.seeded import seeded_inputs
+    from oracle.cft_oracle import OracleModel
+    cfg, model, sd = _seeded("cfg5", 5)
+    rgb, ir = seeded_inputs(1, 1280, 1280, 5)
+    want_pred, want_raw = OracleModel(cfg)(sd, rgb, ir)
+    model.fuse()
+    pred, raw = _run(model, rgb, ir, dev, torch.float32)
+    assert pred.shape == (1, 100800, 8)
+    _check_fp32(pred, raw, want_pred, want_raw)
+    pred, raw = _run(model, rgb, ir, dev, torch.float16)
+    _check_f16(pred, raw, want_pred, want_raw)
+
+
+# ------------------------------------------------------------------------- structural properties
 def test_unfused_equals_fused(dev):
     """BN folding happens at pack time either way: model.fuse() must not change the outputs."""
     g, cfg, model, rgb, ir = load_case([p for p in GOLDEN if p.endswith("s_x3_rect.pt")][0])
@@ -66,7 +184,7 @@ def test_unfused_equals_fused(dev):
     assert torch.allclose(p0, p1, rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_graph_replay_is_bit_identical_to_eager(dev, dtype):
     g, cfg, model, rgb, ir = load_case([p for p in GOLDEN if p.endswith("s_1cft_256.pt")][0])
     model = model.to(dev).set_compute_dtype(dtype)
@@ -81,15 +199,39 @@ def test_graph_replay_is_bit_identical_to_eager(dev, dtype):
     model.release_graphs()
 
 
+def test_captured_graph_is_dropped_when_weights_change(dev):
+    """a captured graph replays the packed weights of capture time; in-place weight updates,
+    load_state_dict and .to()/.half() must not return detections of the old weights."""
+    from msod_amd.utils.seeded import seeded_state_dict
+    g, cfg, model, rgb, ir = load_case([p for p in GOLDEN if p.endswith("s_add_320.pt")][0])
+    model = model.to(dev).set_compute_dtype(torch.float32)
+    x, x2 = rgb.to(dev), ir.to(dev)
+    with torch.no_grad():
+        model.capture(rgb.shape[0], rgb.shape[2], rgb.shape[3])
+        before = model(x, x2)[0].clone()
+        assert len(model._graphs) == 1
+        sd2 = seeded_state_dict(model.state_dict(), 77)
+        model.load_state_dict(sd2)                         # invalidates explicitly
+        assert len(model._graphs) == 0
+        after = model(x, x2)[0].clone()
+        from msod_amd.models.yolo_test import Model
+        fresh = Model(cfg)
+        fresh.load_state_dict(sd2)
+        want = fresh.to(dev).set_compute_dtype(torch.float32)(x, x2)[0]
+        assert not torch.equal(before, after) and torch.equal(after, want)
+        model.capture(rgb.shape[0], rgb.shape[2], rgb.shape[3])
+        next(model.parameters()).mul_(1.5)                 # in-place update: caught by the version fingerprint at replay
+        third = model(x, x2)[0]
+        assert len(model._graphs) == 0 and not torch.equal(third, after)
+    torch.cuda.synchronize()
+
+
 def test_pairs_are_independent_at_full_shape(dev):
     """Size-independent property at the BASELINE shape (yolov5l+CFTx3, 640x640): the forward of a pair
     does not depend on its batch-mates, so pair 5 of a batch of 8 equals the same pair run alone
     (different tile shapes / grid sizes, same arithmetic per pixel)."""
-    from msod_amd.models.configs import named_config
-    from msod_amd.models.yolo_test import Model
-    from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict
-    model = Model(named_config("cfg3"))
-    model.load_state_dict(seeded_state_dict(model.state_dict(), 11))
+    from msod_amd.utils.seeded import seeded_inputs
+    cfg, model, sd = _seeded("cfg3", 11)
     model = model.to(dev).fuse().set_compute_dtype(torch.bfloat16)
     rgb, ir = seeded_inputs(8, 640, 640, 11)
     with torch.no_grad():
@@ -103,40 +245,93 @@ def test_pairs_are_independent_at_full_shape(dev):
     assert (full[..., 4:] >= 0).all() and (full[..., 4:] <= 1).all()
 
 
-def test_uint8_pair_input_equals_float_input(dev):
+# ------------------------------------------------------------------------- boundary: inputs the reference's callers hold
+def test_uint8_pair_input_matches_oracle_on_normalised_floats(dev):
     """Caller-side pre-processing: the model accepts the uint8 RGB / IR views of the
-    reference's [B,6,H,W] batch directly; result = forward of `.float()/255` (reference test.py:106-113)."""
+    reference's [B,6,H,W] batch directly; compared with the ORACLE evaluated on `img.float()/255`
+    (reference test.py:106-113), in fp32 (tight) and fp16 (1e-2)."""
+    from oracle.cft_oracle import OracleModel
     g, cfg, model, rgb, ir = load_case([p for p in GOLDEN if p.endswith("s_x3_320.pt")][0])
     img6 = (torch.cat([rgb, ir], 1) * 255).round().to(torch.uint8)
-    model = model.to(dev).set_compute_dtype(torch.float32)
+    f = img6.float() / 255.0
+    want_pred, want_raw = OracleModel(cfg)(model.state_dict(), f[:, :3], f[:, 3:])
+    d6 = img6.to(dev)
+    for dtype, check in ((torch.float32, _check_fp32), (torch.float16, _check_f16)):
+        model = model.to(dev).set_compute_dtype(dtype)
+        with torch.no_grad():
+            p8, r8 = model(d6[:, :3], d6[:, 3:])
+        torch.cuda.synchronize()
+        check(p8.cpu(), [r.cpu() for r in r8], want_pred, want_raw)
+
+
+def test_model_half_with_half_images_like_the_reference_callers(dev):
+    """test.py:66-68 / detect_twostream.py:40-41: `model.half()` then `img.half()` inputs."""
+    from oracle.cft_oracle import OracleModel
+    g, cfg, model, rgb, ir = load_case([p for p in GOLDEN if p.endswith("s_1cft_256.pt")][0])
+    want_pred, want_raw = OracleModel(cfg)(model.state_dict(), rgb, ir)
+    model = model.to(dev).half()
+    assert model.compute_dtype == torch.float16 and next(model.parameters()).dtype == torch.float16
     with torch.no_grad():
-        d6 = img6.to(dev)
-        p8, _ = model(d6[:, :3], d6[:, 3:])
-        f = (img6.float() / 255.0).to(dev)
-        pf, _ = model(f[:, :3].contiguous(), f[:, 3:].contiguous())
+        pred, raw = model(rgb.to(dev).half(), ir.to(dev).half())
     torch.cuda.synchronize()
-    assert torch.allclose(p8.cpu(), pf.cpu(), rtol=1e-4, atol=1e-3)
+    assert pred.dtype == torch.float32                       # detections stay fp32 (Detect logits come out of the GEMM in fp32)
+    _check_f16(pred.cpu(), [r.cpu() for r in raw], want_pred, want_raw)
+    model.float()
+    assert model.compute_dtype == torch.float32
+
+
+def test_reference_pickled_checkpoint_runs_on_gpu(dev):
+    """a checkpoint pickled by the REFERENCE's own classes (tests/golden/ref_ckpt_tiny.pt, written
+    by make_golden.py `ckpt` in the build container exactly as train.py:850-860 does) goes through
+    compat.attempt_load (= models/experimental.py:113-134) and its forward matches the reference's recorded
+    outputs and the oracle; also the list / Ensemble form."""
+    from msod_amd import compat
+    from oracle.cft_oracle import OracleModel
+    from msod_amd.utils.seeded import seeded_inputs
+    ck = os.path.join(HERE, "golden", "ref_ckpt_tiny.pt")
+    out = torch.load(os.path.join(HERE, "golden", "ref_ckpt_tiny_out.pt"), weights_only=False)
+    model = compat.attempt_load(ck, map_location="cpu")
+    assert type(model).__module__.startswith("msod_amd") and model.compute_dtype == torch.float32
+    assert model.names == out["names"] and torch.equal(model.stride, out["stride"])
+    rgb, ir = seeded_inputs(out["batch"], out["height"], out["width"], out["seed"])
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    want_pred, want_raw = OracleModel(out["cfg"])(sd, rgb, ir)
+    model = model.to(dev)
+    with torch.no_grad():
+        pred, raw = model(rgb.to(dev), ir.to(dev))
+    pred, raw = pred.cpu(), [r.cpu() for r in raw]
+    _check_fp32(pred, raw, want_pred, want_raw)
+    _check_fp32(pred, raw, out["pred"], out["raw"])           # the reference's own forward of the same checkpoint
+    with torch.no_grad():
+        model.half()
+        p16, r16 = model(rgb.to(dev).half(), ir.to(dev).half())
+    _check_f16(p16.cpu(), [r.cpu() for r in r16], out["pred"], out["raw"])
+    ens = compat.attempt_load([ck, ck], map_location="cpu").to(dev)
+    assert type(ens).__name__ == "Ensemble" and len(ens) == 2 and ens.names == out["names"]
+    with torch.no_grad():
+        y, none = ens(rgb.to(dev), ir.to(dev))
+    assert none is None and y.shape == (out["batch"], 2 * out["pred"].shape[1], out["pred"].shape[2])
+    n = out["pred"].shape[1]
+    assert torch.allclose(y[:, :n].cpu(), out["pred"], rtol=1e-3, atol=1e-3) and torch.equal(y[:, :n], y[:, n:])
+    import sys
+    for name in ("models", "models.common", "models.yolo_test"):
+        sys.modules.pop(name, None)
 
 
 @pytest.mark.parametrize("shape", [(1, 64, 96), (3, 96, 64), (5, 32, 32)], ids=["b1_rect", "b3_rect", "b5_min"])
 def test_small_odd_shapes_match_oracle(dev, shape):
     """Batch 1 / odd batches, the smallest legal image (32x32: 1x1 P5 maps, adaptive pooling windows that
-    repeat pixels, bilinear upsampling from 8x8 DOWN to 1x1) and non-square inputs, fp32 vs the oracle."""
-    from msod_amd.models.configs import named_config
-    from msod_amd.models.yolo_test import Model
-    from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict
+    repeat pixels, bilinear upsampling from 8x8 DOWN to 1x1) and non-square inputs, fp32 + fp16 vs the oracle."""
+    from msod_amd.utils.seeded import seeded_inputs
     from oracle.cft_oracle import OracleModel
     b, h, w = shape
-    cfg = named_config("yolov5s_fusion_transformerx3_vedai")
-    model = Model(cfg)
-    sd = seeded_state_dict(model.state_dict(), 21)
-    model.load_state_dict(sd)
+    cfg, model, sd = _seeded("yolov5s_fusion_transformerx3_vedai", 21)
     rgb, ir = seeded_inputs(b, h, w, 21)
     want_pred, want_raw = OracleModel(cfg)(sd, rgb, ir)
     pred, raw = _run(model, rgb, ir, dev, torch.float32)
-    for a, c in zip(raw, want_raw):
-        assert a.shape == c.shape and (a - c).abs().max().item() <= 1e-3
-    assert torch.allclose(pred, want_pred, rtol=1e-3, atol=1e-3)
+    _check_fp32(pred, raw, want_pred, want_raw)
+    pred, raw = _run(model, rgb, ir, dev, torch.float16)
+    _check_f16(pred, raw, want_pred, want_raw)
 
 
 def test_bad_image_sizes_raise(dev):
@@ -152,21 +347,15 @@ def test_bad_image_sizes_raise(dev):
 def test_yolov5x_four_cft_blocks_matches_oracle(dev):
     """Reference yaml `yolov5x_fusion_transformer_FLIR` (depth 1.33 / width 1.25, FOUR GPT blocks): channel counts
     80/160/320/640/1280 exercise K steps that straddle taps, N tails (160, 320 are not multiples of the 128/256
-    tiles) and zero-padded attention heads (d=160 -> head width 20 -> 32).  fp32 vs the oracle."""
-    from msod_amd.models.configs import named_config
-    from msod_amd.models.yolo_test import Model
-    from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict
+    tiles) and zero-padded attention heads (d=160 -> head width 20 -> 32).  fp32 / fp16 / bf16 vs the oracle."""
+    from msod_amd.utils.seeded import seeded_inputs
     from oracle.cft_oracle import OracleModel
-    cfg = named_config("yolov5x_fusion_transformer_FLIR")
-    model = Model(cfg)
-    sd = seeded_state_dict(model.state_dict(), 31)
-    model.load_state_dict(sd)
+    cfg, model, sd = _seeded("yolov5x_fusion_transformer_FLIR", 31)
     rgb, ir = seeded_inputs(1, 128, 160, 31)
     want_pred, want_raw = OracleModel(cfg)(sd, rgb, ir)
     pred, raw = _run(model, rgb, ir, dev, torch.float32)
-    for a, c in zip(raw, want_raw):
-        assert a.shape == c.shape and (a - c).abs().max().item() <= 1e-3
-    assert torch.allclose(pred, want_pred, rtol=1e-3, atol=1e-3)
-    pred16, raw16 = _run(model, rgb, ir, dev, torch.bfloat16)
-    a = torch.cat([r.reshape(-1) for r in raw16]); b = torch.cat([r.reshape(-1) for r in want_raw])
-    assert ((a - b).pow(2).mean().sqrt() / b.std()).item() <= BF16_LOGIT_RMS
+    _check_fp32(pred, raw, want_pred, want_raw)
+    pred16, raw16 = _run(model, rgb, ir, dev, torch.float16)
+    _check_f16(pred16, raw16, want_pred, want_raw)
+    predb, rawb = _run(model, rgb, ir, dev, torch.bfloat16)
+    _check_bf16(predb, rawb, want_pred, want_raw)

@@ -10,10 +10,12 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import bf16_round, rel_err, to_cpu_f32, to_dev_nhwc, tol
+from helpers import rel_err, to_cpu_f32, to_dev_nhwc, tol
 
 pytestmark = pytest.mark.gpu
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+DTYPE_IDS = ["f32", "bf16", "f16"]
+LOWP = [torch.bfloat16, torch.float16]
 
 
 def _rnd(*shape, seed=0, scale=1.0):
@@ -22,7 +24,7 @@ def _rnd(*shape, seed=0, scale=1.0):
 
 
 def _q(x, dtype):
-    return x if dtype == torch.float32 else bf16_round(x)
+    return x if dtype == torch.float32 else x.to(dtype).float()
 
 
 CONV_CASES = [
@@ -40,7 +42,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{i}" for i in range(len(CONV_CASES))])
 def test_conv2d(dev, dtype, case):
     from msod_amd import ops
@@ -62,7 +64,7 @@ def test_conv2d(dev, dtype, case):
     assert rel_err(got, ref) < tol(dtype), f"rel err {rel_err(got, ref):.3e}"
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 def test_conv2d_channel_slices_and_fp32_out(dev, dtype):
     """Input read from a channel slice, output written into a slice of a wider buffer, residual
     aliasing the output (the C3 / Bottleneck pattern), and bf16-in / fp32-out (Detect, GPT)."""
@@ -86,7 +88,7 @@ def test_conv2d_channel_slices_and_fp32_out(dev, dtype):
     assert rel_err(to_cpu_f32(y32), F.conv2d(xin, w, b, 1, 1)) < 2e-5 * (1 if dtype == torch.float32 else 50)
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 def test_linear_residual_fp32_stream(dev, dtype):
     """nn.Linear + bias + fp32 residual updated in place (CFT out-proj / fc2 epilogue)."""
     from msod_amd import ops
@@ -104,7 +106,7 @@ def test_linear_residual_fp32_stream(dev, dtype):
     assert rel_err(out.cpu(), ref) < 2e-5 * (1 if dtype == torch.float32 else 20)
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 def test_focus(dev, dtype):
     from msod_amd import ops
     from oracle import cft_oracle as O
@@ -123,7 +125,7 @@ def test_focus(dev, dtype):
     assert rel_err(to_cpu_f32(y), O.focus(sd, "f.", _q(img, dtype), 3, 1)) < tol(dtype)
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 @pytest.mark.parametrize("hw", [(20, 20), (7, 12), (40, 40)])
 def test_spp_maxpool(dev, dtype, hw):
     from msod_amd import ops
@@ -141,7 +143,7 @@ def test_spp_maxpool(dev, dtype, hw):
     assert torch.equal(got[:, :C], x)
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 def test_copy_upsample_add(dev, dtype):
     from msod_amd import ops
     a = _q(_rnd(2, 32, 6, 10, seed=16), dtype)
@@ -159,7 +161,7 @@ def test_copy_upsample_add(dev, dtype):
     assert rel_err(to_cpu_f32(s), ref + c) < tol(dtype)
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 @pytest.mark.parametrize("hw", [(80, 80), (20, 20), (12, 20), (8, 8), (5, 7)])
 def test_gpt_tokenize_and_upsample(dev, dtype, hw):
     """adaptive avg-pool (overlapping windows at 20->8, rectangular maps, maps smaller than 8x8)
@@ -195,12 +197,14 @@ def test_layernorm(dev, C):
     ref = F.layer_norm(x, (C,), g, b, 1e-5)
     y = ops.layernorm(x.to(dev), g.to(dev), b.to(dev), torch.float32)
     yb = ops.layernorm(x.to(dev), g.to(dev), b.to(dev), torch.bfloat16)
+    yh = ops.layernorm(x.to(dev), g.to(dev), b.to(dev), torch.float16)
     torch.cuda.synchronize()
     assert rel_err(y.cpu(), ref) < 1e-5
     assert rel_err(yb.float().cpu(), ref) < 5e-3
+    assert rel_err(yh.float().cpu(), ref) < 6e-4
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 @pytest.mark.parametrize("d_model", [64, 256, 512, 1024, 1280, 160])
 def test_self_attention_module(dev, dtype, d_model):
     """SelfAttention (fused QKV GEMM + attention core + out-proj) against the oracle; covers head
@@ -221,8 +225,9 @@ def test_self_attention_module(dev, dtype, d_model):
     y = sa(x.view(B * 128, d_model).to(dev).to(dtype))
     torch.cuda.synchronize()
     got = to_cpu_f32(y).view(B, 128, -1)[..., :d_model]
-    # bf16: q,k,v, P and the attention output are each rounded once -> a few 2^-8 steps
-    assert rel_err(got, ref) < (5e-5 if dtype == torch.float32 else 3e-2), f"rel err {rel_err(got, ref):.3e}"
+    # 16-bit: q,k,v, P and the attention output are each rounded once -> a few 2^-8 (bf16) / 2^-11 (fp16) steps
+    lim = {torch.float32: 5e-5, torch.bfloat16: 3e-2, torch.float16: 4e-3}[dtype]
+    assert rel_err(got, ref) < lim, f"rel err {rel_err(got, ref):.3e}"
 
 
 def test_detect_decode(dev):
@@ -257,13 +262,15 @@ def test_errors_are_loud(dev):
     with pytest.raises(RuntimeError):
         ops.conv2d(torch.zeros(1, 8, 4, 4, dtype=torch.bfloat16), pk, 0)     # CPU tensor
     with pytest.raises(TypeError):
-        ops.conv2d(torch.zeros(1, 8, 4, 4, device=dev, dtype=torch.float16), pk, 0)
+        ops.conv2d(torch.zeros(1, 8, 4, 4, device=dev, dtype=torch.float64), pk, 0)
+    with pytest.raises(RuntimeError, match="compute dtype"):
+        ops.conv2d(torch.zeros(1, 8, 4, 4, device=dev, dtype=torch.float16), pk, 0, out_dtype=torch.bfloat16)   # fp16 in, bf16 out
 
 
 TILE_VARIANTS = [1, 2, 4, 6, 7, 8, 23, 27, 30, 32, 33, 51, 60, 63, 70, 71, 72, 73, 74, 75]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 @pytest.mark.parametrize("variant", TILE_VARIANTS)
 def test_conv2d_every_tile_configuration(dev, dtype, variant):
     """Every tile configuration of the GEMM family (incl. the 16-wave 256x256 / 512x128 ones that the
@@ -287,7 +294,7 @@ def test_conv2d_every_tile_configuration(dev, dtype, variant):
     assert rel_err(to_cpu_f32(y), ref) < tol(dtype), f"variant {variant}: rel err {rel_err(to_cpu_f32(y), ref):.3e}"
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 def test_focus_uint8_pair(dev, dtype):
     """The reference's callers hold the pair as one uint8 [B,6,H,W] tensor (test.py:106-113); slicing it and
     handing the uint8 views to Focus must equal `.float()/255` + split + the fp32 Focus path."""
@@ -299,19 +306,19 @@ def test_focus_uint8_pair(dev, dtype):
         z8 = ops.focus_s2d(d6[:, lo:lo + 3], dtype)
         zf = ops.focus_s2d(ref[:, lo:lo + 3].contiguous().to(dev), dtype)
         torch.cuda.synchronize()
-        assert rel_err(to_cpu_f32(z8), to_cpu_f32(zf)) < (1e-6 if dtype == torch.float32 else 4e-3)
+        assert rel_err(to_cpu_f32(z8), to_cpu_f32(zf)) < (1e-6 if dtype == torch.float32 else tol(dtype))
 
 
+@pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
 @pytest.mark.parametrize("n", [32, 48, 64, 80])
 @pytest.mark.parametrize("hw", [(32, 32), (96, 160), (40, 296)])
-def test_focus_conv_fused_is_bit_identical(dev, n, hw):
+def test_focus_conv_fused_is_bit_identical(dev, n, hw, dtype):
     """cft_focus_conv (image -> space-to-depth -> 3x3 conv -> SiLU in one kernel) against the two-kernel path
     (cft_focus_s2d + cft_conv2d), for float and uint8 images: same products, same k order -> same bits; and
     against the oracle's Focus within the bf16 tolerance."""
     from msod_amd import ops
     from oracle import cft_oracle as O
     H, W = hw
-    dtype = torch.bfloat16
     g = torch.Generator().manual_seed(50 + n)
     sd = {"f.conv.conv.weight": _q(_rnd(n, 12, 3, 3, seed=51, scale=0.1), dtype), "f.conv.conv.bias": _rnd(n, seed=52, scale=0.1)}
     pk = ops.pack_conv(sd["f.conv.conv.weight"], sd["f.conv.conv.bias"], dtype, cin_pad=16, device=dev)
@@ -331,18 +338,22 @@ def test_focus_conv_fused_is_bit_identical(dev, n, hw):
     y = ops.focus_conv(img.to(dev), pk, 1, dtype)
     torch.cuda.synchronize()
     assert rel_err(to_cpu_f32(y), O.focus(sd, "f.", _q(img, dtype), 3, 1)) < tol(dtype)
+    if dtype == torch.float16:          # half images (`img.half()`, reference test.py:107) feed the fused kernel directly
+        yh = ops.focus_conv(img.to(dev).half(), pk, 1, dtype)
+        torch.cuda.synchronize()
+        assert rel_err(to_cpu_f32(yh), O.focus(sd, "f.", img.half().float(), 3, 1)) < tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
 @pytest.mark.parametrize("shortcut", [True, False])
 @pytest.mark.parametrize("hw", [(8, 32), (24, 40), (40, 72)])
-def test_bottleneck_fused_is_bit_identical(dev, shortcut, hw):
+def test_bottleneck_fused_is_bit_identical(dev, shortcut, hw, dtype):
     """cft_bottleneck (1x1 -> SiLU -> 3x3 -> SiLU -> + shortcut in one kernel, 64 channels) against the two
     cft_conv2d launches it replaces: same bits; input and output as channel slices of wider buffers; and against
     the oracle's bottleneck within the bf16 tolerance."""
     from msod_amd import ops
     from oracle import cft_oracle as O
     H, W = hw
-    dtype = torch.bfloat16
     sd = {"m.cv1.conv.weight": _q(_rnd(64, 64, 1, 1, seed=61, scale=0.15), dtype), "m.cv1.conv.bias": _rnd(64, seed=62, scale=0.1),
           "m.cv2.conv.weight": _q(_rnd(64, 64, 3, 3, seed=63, scale=0.05), dtype), "m.cv2.conv.bias": _rnd(64, seed=64, scale=0.1)}
     pk1 = ops.pack_conv(sd["m.cv1.conv.weight"], sd["m.cv1.conv.bias"], dtype, device=dev)
@@ -366,7 +377,7 @@ def test_bottleneck_fused_is_bit_identical(dev, shortcut, hw):
     assert rel_err(to_cpu_f32(fused), ref) < 2 * tol(dtype)   # two bf16 roundings (hidden tensor, output)
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 @pytest.mark.parametrize("ks", [(5, 9, 13), (3, 5, 7), (3, 5, 9), (5, 7, 13)])
 def test_spp_maxpool_kernel_sizes(dev, dtype, ks):
     """Chained fast path (k, 2k-1, 3k-2) and the generic kernel: both exact against F.max_pool2d, on a
@@ -383,3 +394,22 @@ def test_spp_maxpool_kernel_sizes(dev, dtype, ks):
     for i, k in enumerate(ks):
         assert torch.equal(got[:, (i + 1) * C:(i + 2) * C], F.max_pool2d(x, k, 1, k // 2)), f"k={k}"
     assert torch.equal(got[:, :C], x)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
+def test_plain_nchw_tensor_into_a_module(dev, dtype):
+    """Boundary: a module of models/common.py called with an ordinary contiguous NCHW tensor (as the reference's
+    modules are) converts it with the cft_to_nhwc kernel - no ATen copy - and computes the same as on NHWC input;
+    also the dtype-converting form (fp32 NCHW -> compute dtype NHWC with zero channel padding)."""
+    from msod_amd import ops
+    x = _q(_rnd(2, 32, 9, 11, seed=80), dtype)
+    w = _q(_rnd(16, 32, 3, 3, seed=81, scale=0.08), dtype)
+    pk = ops.pack_conv(w, None, dtype, device=dev)
+    y_nchw = ops.conv2d(x.to(dev).to(dtype), pk, 1)                      # contiguous NCHW in
+    y_nhwc = ops.conv2d(to_dev_nhwc(x, dev, dtype), pk, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(y_nchw.float().cpu(), y_nhwc.float().cpu())
+    z = ops.to_nhwc(_rnd(2, 12, 5, 7, seed=82).to(dev), dtype, cpad=16)   # fp32 NCHW, 12 -> 16 channels
+    torch.cuda.synchronize()
+    assert z.shape == (2, 16, 5, 7) and z.stride(1) == 1
+    assert torch.equal(z[:, :12].float().cpu(), _q(_rnd(2, 12, 5, 7, seed=82), dtype)) and z[:, 12:].abs().max() == 0

@@ -64,3 +64,58 @@ def test_hip_nms_edge_cases(dev):
     assert torch.equal(dets[0, :, 5].cpu(), torch.arange(300).float())   # descending confidence = ascending class here
     dets, counts = batched_nms(p, 0.25, 0.45, agnostic=True)
     assert int(counts[0]) == 1                                    # identical boxes collapse when class-agnostic
+
+
+def _random_pred(rows, nc, seed, spread=600.0):
+    g = torch.Generator().manual_seed(seed)
+    p = torch.zeros(1, rows, nc + 5)
+    p[0, :, 0:2] = torch.rand(rows, 2, generator=g) * spread
+    p[0, :, 2:4] = torch.rand(rows, 2, generator=g) * 40 + 8
+    p[0, :, 4] = torch.rand(rows, generator=g) * 0.5 + 0.5
+    p[0, :, 5:] = torch.rand(rows, nc, generator=g)
+    return p
+
+
+def test_nms_oracle_max_nms_and_labels_branches():
+    """The oracle's restatement of the two reference branches the golden cases do not reach: the max_nms
+    pre-truncation (utils/general.py:515-516) and the autolabelling rows (:480-487)."""
+    p = _random_pred(300, 3, 1)
+    full = nms_oracle.non_max_suppression(p, 0.05, 0.45, multi_label=True)[0]
+    cut = nms_oracle.non_max_suppression(p, 0.05, 0.45, multi_label=True, max_nms=200)[0]
+    assert cut.shape[0] <= full.shape[0] and cut[:, 4].min() >= full[:, 4].min()
+    kth = torch.sort((p[0, :, 5:] * p[0, :, 4:5]).reshape(-1), descending=True)[0][199]
+    assert cut[:, 4].min() >= kth
+    lab = [torch.tensor([[2.0, 300.0, 300.0, 50.0, 60.0]])]
+    out = nms_oracle.non_max_suppression(p, 0.25, 0.45, labels=lab)[0]
+    assert out[0, 4] == 1.0 and out[0, 5] == 2.0 and torch.allclose(out[0, :4], torch.tensor([275.0, 270.0, 325.0, 330.0]))
+
+
+@pytest.mark.gpu
+def test_hip_nms_class_filter_is_exact_beyond_64_classes(dev):
+    """`classes=` must filter exactly for any class id (80-class heads), reference :505-506."""
+    from msod_amd.utils.general import non_max_suppression
+    p = _random_pred(500, 80, 2)
+    for classes in ([70], [3], [3, 64, 79], []):
+        want = nms_oracle.non_max_suppression(p, 0.25, 0.45, classes=classes)[0]
+        got = non_max_suppression(p.to(dev), 0.25, 0.45, classes=classes)[0].cpu()
+        assert got.shape == want.shape and torch.allclose(got, want, rtol=0, atol=1e-4)
+        assert all(int(c) in classes for c in got[:, 5].tolist())
+
+
+@pytest.mark.gpu
+def test_hip_nms_max_nms_truncation_and_labels(dev):
+    from msod_amd.utils.general import batched_nms, non_max_suppression
+    p = _random_pred(2000, 3, 3, spread=4000.0)            # spread out: little suppression, many survivors
+    want = nms_oracle.non_max_suppression(p, 0.05, 0.45, multi_label=True, max_nms=1000)[0]
+    dets, counts = batched_nms(p.to(dev), 0.05, 0.45, multi_label=True, max_nms=1000)
+    got = dets[0, :int(counts[0])].cpu()
+    assert got.shape == want.shape and torch.allclose(got, want, rtol=0, atol=1e-4)
+    # the truncation really bites here: without it lower-confidence boxes survive
+    dets2, counts2 = batched_nms(p.to(dev), 0.05, 0.45, multi_label=True, max_nms=0)
+    assert int(counts2[0]) == 300 and int(counts[0]) == 300
+    lab = [torch.tensor([[2.0, 300.0, 300.0, 50.0, 60.0], [0.0, 900.0, 100.0, 30.0, 30.0]])]
+    p1 = _random_pred(300, 3, 4)
+    want = nms_oracle.non_max_suppression(p1, 0.25, 0.45, labels=lab)[0]
+    got = non_max_suppression(p1.to(dev), 0.25, 0.45, labels=lab)[0].cpu()
+    assert got.shape == want.shape and torch.allclose(got[2:], want[2:], rtol=0, atol=1e-4)
+    assert sorted(got[:2, 5].tolist()) == [0.0, 2.0] and (got[:2, 4] == 1.0).all()      # the two labels tie at conf 1.0
