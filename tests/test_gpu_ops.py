@@ -267,7 +267,7 @@ def test_errors_are_loud(dev):
         ops.conv2d(torch.zeros(1, 8, 4, 4, device=dev, dtype=torch.float16), pk, 0, out_dtype=torch.bfloat16)   # fp16 in, bf16 out
 
 
-TILE_VARIANTS = [1, 2, 4, 6, 7, 8, 23, 27, 30, 32, 33, 51, 60, 63, 70, 71, 72, 73, 74, 75]
+TILE_VARIANTS = [1, 2, 4, 6, 7, 8, 23, 27, 30, 32, 33, 51, 60, 63, 70, 71, 72, 73, 74, 75, 80, 81]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
@@ -413,3 +413,46 @@ def test_plain_nchw_tensor_into_a_module(dev, dtype):
     torch.cuda.synchronize()
     assert z.shape == (2, 16, 5, 7) and z.stride(1) == 1
     assert torch.equal(z[:, :12].float().cpu(), _q(_rnd(2, 12, 5, 7, seed=82), dtype)) and z[:, 12:].abs().max() == 0
+
+
+STAGGERED_CASES = [
+    # B, H, W, Cin, Cout, k, s, residual          (variants 80 / 81: the staggered two-group kernels)
+    (2, 33, 31, 64, 320, 3, 1, True),       # ragged M, N tail over three / two tiles, border taps
+    (3, 20, 20, 32, 256, 3, 2, False),      # Cin < K step: several taps per K tile (the non-branch-free advance), stride 2
+    (1, 16, 16, 1024, 512, 1, 1, False),    # 1x1, long K (16 K tiles)
+    (2, 12, 12, 128, 128, 3, 1, True),      # the 128-channel Bottleneck shape
+    (1, 9, 11, 80, 160, 3, 1, False),       # K = 720 -> Kpad 768: K tail inside the last tile, taps straddle K tiles
+    (1, 8, 8, 64, 8, 1, 1, False),          # ONE K tile (shorter than the prologue's run-ahead), N = 8
+]
+
+
+@pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
+@pytest.mark.parametrize("variant", [80, 81])
+@pytest.mark.parametrize("case", STAGGERED_CASES, ids=[f"s{i}" for i in range(len(STAGGERED_CASES))])
+def test_staggered_group_kernels_are_bit_identical(dev, dtype, variant, case):
+    """conv_gemm8 / conv_gemm8n (two wave groups one barrier apart, counted vmcnt, 2 / 3 LDS buffers) against the
+    plain 128x128 kernel (variant 2): same fragments, same k order -> same bits, on shapes that stress the K-tile
+    run-ahead (1 .. 18 K tiles, K tails, zero-page tiles beyond K, taps that straddle tiles) and the tile edges."""
+    from msod_amd import _lib, ops
+    B, H, W, Cin, Cout, k, s_, use_res = case
+    x = _q(_rnd(B, Cin, H, W, seed=91), dtype)
+    w = _q(_rnd(Cout, Cin, k, k, seed=92, scale=1.0 / math.sqrt(Cin * k * k)), dtype)
+    b = _rnd(Cout, seed=93, scale=0.5)
+    pk = ops.pack_conv(w, b, dtype, s=s_, device=dev)
+    xd = to_dev_nhwc(x, dev, dtype)
+    lib = _lib.load()
+    outs = {}
+    for v in (2, variant):
+        lib.cft_set_conv_variant(v)
+        try:
+            y0 = ops.conv2d(xd, pk, 1)
+            res = y0.clone() if use_res else None
+            outs[v] = ops.conv2d(xd, pk, 1, residual=res)
+            torch.cuda.synchronize()
+        finally:
+            lib.cft_set_conv_variant(0)
+    assert torch.equal(outs[2].float().cpu(), outs[variant].float().cpu())
+    ref = F.silu(F.conv2d(x, w, b, s_, k // 2))
+    got = to_cpu_f32(outs[variant])[:, :Cout]
+    if not use_res:
+        assert rel_err(got, ref) < tol(dtype)

@@ -60,11 +60,13 @@ def main():
     ap.add_argument("--variants", default="1,2,5,9")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
+    ap.add_argument("--out", default="gemm_bench.json")
+    ap.add_argument("--dtype", default="bf16")
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
     dev = torch.device("cuda:0")
     lib = _lib.load()
-    dtype = torch.bfloat16
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
     results = []
     g = torch.Generator().manual_seed(0)
     for name, B, H, W, Cin, N, k, s, use_res, count in SHAPES:
@@ -108,7 +110,7 @@ def main():
         results.append(rec)
         del x, res
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "gemm_bench.json"), "w") as fh:
+    with open(os.path.join(ROOT, "gpurun_out", args.out), "w") as fh:
         json.dump(results, fh, indent=1)
     # summary: time per forward per variant
     for v in variants:
