@@ -125,11 +125,11 @@ int cft_copy_channels(const void* in, int ldi, int ioff, void* out, int ldo, int
 
 /*
  * Layout / dtype conversion at the boundary: any strided [B,C,H,W] tensor (in_dtype, element strides) -> NHWC
- * channel slice [ooff, ooff + pad(C)) of `out` in `dtype`, padding channels zero.  This is what lets a module of
+ * channel slice [ooff, ooff + cpad) of `out` in `dtype`, channels [C, cpad) zero (cpad a granule multiple).  This is what lets a module of
  * models/common.py be called with an ordinary NCHW torch tensor (as the reference's modules are) without ATen.
  */
 int cft_to_nhwc(const void* in, int in_dtype, long stride_b, long stride_c, long stride_h, long stride_w,
-                void* out, int ldo, int ooff, int B, int C, int H, int W, int dtype, void* stream);
+                void* out, int ldo, int ooff, int B, int C, int cpad, int H, int W, int dtype, void* stream);
 
 /* Elementwise out = a + b over M pixels x C channels (Add / Add2, models/common.py:228-243). */
 int cft_add(const void* a, int lda, int aoff, const void* b, int ldb, int boff,
@@ -189,7 +189,7 @@ int cft_detect_decode(const float* logits, int ldl, float* raw, float* pred, con
  * pre-truncation to the highest confidences (:469,:515-516; 0 = off), per-class greedy NMS (class offset
  * 4096 px unless agnostic) with IoU > iou_thres suppression, at most max_det detections.
  *   pred    : float [B, rows, no]            dets : float [B, max_det, 6] (x1,y1,x2,y2,conf,cls), first counts[b] rows valid
- *   scratch : >= B * rows * (multi_label ? no-5 : 1) * 32 bytes of device memory
+ *   scratch : >= B * round_up(rows * (multi_label ? no-5 : 1), 4) * 32 bytes of device memory, 16-byte aligned
  */
 int cft_nms(const float* pred, int B, int rows, int no, float conf_thres, float iou_thres,
             int agnostic, int multi_label, const unsigned char* class_allow, int max_det, int max_nms,

@@ -34,6 +34,24 @@ def install_reference_aliases(force=False):
     return pkg
 
 
+def install_common_alias(force=False):
+    """Strict form of the drop-in: ONLY ``models.common`` resolves to this package; the
+    reference's own graph file ``models/yolo_test.py`` (its ``Model`` / ``parse_model`` / ``forward_once`` /
+    ``Detect``) is imported unchanged from the reference tree, which must be on ``sys.path``.  The modules then
+    compute in the precision of their parameters (fp32, or fp16 after ``model.half()``), because the reference's
+    ``Detect`` and ``nn.Upsample`` are torch modules that see the activations."""
+    from .models import common
+    if "models.common" in sys.modules and sys.modules["models.common"] is not common and not force:
+        raise RuntimeError("models.common is already imported from "
+                           f"{getattr(sys.modules['models.common'], '__file__', '?')}; pass force=True to override it")
+    import importlib
+    sys.modules.pop("models", None)
+    pkg = importlib.import_module("models")          # the reference's package (namespace or regular)
+    sys.modules["models.common"] = common
+    pkg.common = common
+    return common
+
+
 def _ensemble_class():
     import torch
     import torch.nn as nn

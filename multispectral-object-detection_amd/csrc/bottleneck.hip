@@ -17,6 +17,10 @@
 
 extern int g_conv_variant;   // conv_gemm.hip (cft_set_conv_variant)
 
+__device__ __attribute__((aligned(16))) uint32_t cft_zero_page_b[4] = {0u, 0u, 0u, 0u};
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
 struct BneckParams {
   const unsigned char* x;    // bf16 NHWC, ldx channels per pixel, slice offset xoff
   const unsigned char* w1;   // bf16 [C][kpad1]
@@ -227,12 +231,287 @@ __global__ void __launch_bounds__(512) bottleneck_kernel(const BneckParams p) {
 #undef BNECK_FETCH
 }
 
+// ------------------------------------------------------------------------------------ 128 channels
+// The same Bottleneck for the 128-channel stage (yolov5l: 80 x 80 maps, 18 Bottlenecks per forward, as two launches
+// the largest line item of the forward: the 3x3 conv re-stages every input tap through the LDS-DMA path, nine times the
+// activation bytes, and the hidden tensor makes an HBM round trip).  Here the 3x3 weights (288 KiB) no longer fit in
+// LDS, so the roles flip: the ACTIVATIONS stay resident and only weights stream.
+//   * One workgroup (8 waves) per 16 x 16 pixel tile.  The hidden tensor t = SiLU(W1 x + b1) of the 18 x 18 halo patch
+//     is computed once into LDS (two 64-channel planes of 128-byte pixel rows, granule slot ^ (pixel & 7)); the nine taps
+//     of the 3x3 conv are shifted ds_read_b128 of it.  Staging traffic per tile drops from 878 KiB (9 taps of A + W2)
+//     to 320 KiB (W1 + W2), all of it L2 hits.
+//   * W1 (2 K tiles of 64) and W2 (18 K tiles: tap x channel half) stream through a 3-deep ring of 16-KiB LDS buffers
+//     (global_load_lds, source-side swizzle), two tiles ahead of the compute tile, one request per thread per phase;
+//     s_waitcnt vmcnt(2) leaves one tile in flight across the barriers.
+//   * K loop = the staggered two-group schedule of conv_gemm8n_kernel (conv_gemm.hip): two phases per K tile, waves
+//     0-3 / 4-7 one barrier apart so that each SIMD always has one wave in its 16-MFMA segment.  Wave (wmr, wnc) owns
+//     4 tile rows x 64 channels; the eight W2 fragments stay in registers for both phases of a K tile.
+//   * t patch phase: x fragments straight from global memory (requested first thing, 12 x 16 B per lane), W1 is the row
+//     operand so a lane ends up with 4 consecutive channels of one pixel (8-byte LDS writes), zero outside the image.
+//   * epilogue: bias + SiLU -> fp32 strip (aliases the dead t patch) -> 16-byte row vectors -> + shortcut -> 16-bit stores.
+// Every product, the 32-wide k chunks, their order and every rounding are those of the two-launch path: bit-identical.
+struct Bneck128Params {
+  const unsigned char* x;
+  const unsigned char* w1;   // [128][kpad1]
+  const unsigned char* w2;   // [128][kpad2], k = (kh*3 + kw)*128 + ci
+  const float* b1;
+  const float* b2;
+  unsigned char* y;
+  int ldx, xoff, ldy, yoff, kpad1, kpad2;
+  int H, W, tiles_x, tiles_y, shortcut;
+};
+
+template <typename T, int ABL = 0>
+__global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params p) {
+  constexpr int C = 128, TS = 16, PW = TS + 2, NPIX = PW * PW;     // 324 patch pixels
+  constexpr int NRT = (NPIX + 15) / 16;                             // 21 row tiles of the patch
+  constexpr int PLANE = NRT * 16 * 128;                             // one 64-channel plane of the t patch (43008 B)
+  constexpr int RING = 16384;                                       // one K tile of weights: 128 rows x 128 B
+  constexpr int NKT = 2 + 18;                                       // W1 (2) + W2 (9 taps x 2 channel halves)
+  constexpr int SLD = 64 + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sT = smem;                    // [2][NRT*16][128 B]; re-used for the epilogue strips
+  unsigned char* sR = smem + 2 * PLANE;        // [3][128][128 B]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  const int grp = wave >> 2;                   // stagger group (waves w, w + 4 share a SIMD)
+  const int wmr = wave >> 1, wnc = wave & 1;   // main loop: tile rows 4 wmr .. +4, channels 64 wnc .. +64
+  const int tiles = p.tiles_x * p.tiles_y;
+  const int b = blockIdx.x / tiles, tt = blockIdx.x - b * tiles;
+  const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+  const int y0 = ty * TS, x0 = tx * TS;
+  const long img_pix = (long)b * p.H * p.W;
+  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(cft_zero_page_b);
+
+  // ---- x fragments of the halo patch: row tile rt = wave + 8 it, lane = (pixel lrow, k-group lgrp), 4 k chunks of 32
+  gran_t a1[3][4];
+  bool inside[3];
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const int q = (wave + it * 8) * 16 + lrow;
+    const int py = q / PW, px = q - py * PW;
+    const int zy = y0 - 1 + py, zx = x0 - 1 + px;
+    inside[it] = q < NPIX && (unsigned)zy < (unsigned)p.H && (unsigned)zx < (unsigned)p.W;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      gran_t t = {0u, 0u, 0u, 0u};
+      if (inside[it]) t = *reinterpret_cast<const gran_t*>(p.x + ((img_pix + (long)zy * p.W + zx) * p.ldx + p.xoff + ks * 32 + lgrp * 8) * 2);
+      a1[it][ks] = t;
+    }
+  }
+
+  // ---- weight ring: K tile kt = rows n (128) x 64 k; this thread stages rows r0 and r0 + 64, k-granule g
+  const int r0 = tid >> 3, slot_s = tid & 7, g = slot_s ^ (r0 & 7);
+  int st_kt = 0, sb = 0;
+#define BN128_STAGE(part_)                                                                               \
+  {                                                                                                      \
+    const int n_ = r0 + 64 * (part_);                                                                    \
+    const unsigned char* src_;                                                                           \
+    if (st_kt < 2) src_ = p.w1 + ((long)n_ * p.kpad1 + st_kt * 64 + g * 8) * 2;                          \
+    else if (st_kt < NKT) src_ = p.w2 + ((long)n_ * p.kpad2 + (st_kt - 2) * 64 + g * 8) * 2;             \
+    else src_ = zero_page;                                                                               \
+    if constexpr (!(ABL & 8))                                                                            \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(sR + sb * RING + (part_) * 8192 + wave * 1024), 16, 0, 0); \
+    if ((part_) == 1) { ++st_kt; sb = sb == 2 ? 0 : sb + 1; }                                            \
+  }
+#define BN128_BARRIER() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+  BN128_STAGE(0) BN128_STAGE(1)
+  BN128_STAGE(0) BN128_STAGE(1)
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // K tile 0 (and the older x fragments) landed
+  BN128_BARRIER()
+  if (grp == 1) BN128_BARRIER()
+
+  // ---- t^T = W1 x^T on the patch: two K tiles, two phases each (output channels 0-63 / 64-127)
+  const int fb = lrow * 128 + ((lgrp ^ (lrow & 7)) << 4);          // fragment read base inside a ring buffer (row lrow)
+  int cb = 0;
+  f32x4_t acc1[3][8];
+#pragma unroll
+  for (int it = 0; it < 3; ++it)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc1[it][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      gran_t wf[4][2];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = ph * 4 + jj;
+        wf[jj][0] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + fb);
+        wf[jj][1] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + (fb ^ 64));
+      }
+      BN128_STAGE(ph)
+      if (ph == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      BN128_BARRIER()
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int it = 0; it < 3; ++it)
+          if (wave + it * 8 < NRT) {   // wave-uniform
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              if constexpr (!(ABL & 1)) acc1[it][ph * 4 + jj] = mma_granule<T>(wf[jj][ks], a1[it][kt * 2 + ks], acc1[it][ph * 4 + jj]);
+          }
+      __builtin_amdgcn_s_setprio(0);
+      BN128_BARRIER()
+    }
+    cb = cb == 2 ? 0 : cb + 1;
+  }
+  if (grp == 0) BN128_BARRIER()                // both groups aligned again
+  // bias + SiLU -> 16-bit -> t patch (zero outside the image: the 3x3 conv's padding)
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const int rt = wave + it * 8;
+    if (rt < NRT) {
+      const int q = rt * 16 + lrow;
+      const uint32_t keep = inside[it] ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c0 = j * 16 + lgrp * 4;        // first of this lane's 4 channels
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (ABL & 1) ? 0.0f : apply_act<CFT_ACT_SILU>(acc1[it][j][e] + (p.b1 != nullptr ? p.b1[c0 + e] : 0.0f));
+        uint2 w;
+        w.x = Elem<T>::pack2(v[0], v[1]) & keep;
+        w.y = Elem<T>::pack2(v[2], v[3]) & keep;
+        const int cc = c0 & 63;
+        *reinterpret_cast<uint2*>(sT + (c0 >> 6) * PLANE + q * 128 + ((((cc >> 3) ^ (q & 7)) << 4) | ((cc & 7) << 1))) = w;
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  BN128_BARRIER()                                // the whole t patch is visible
+  if (grp == 1) BN128_BARRIER()                  // stagger again
+
+  // ---- 3x3 conv of the t patch: 18 K tiles (tap, channel half), two phases (tile rows 4 wmr + {0,1} / {2,3})
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int fbn = (wnc * 64 + lrow) * 128 + ((lgrp ^ (lrow & 7)) << 4);
+#pragma unroll 1
+  for (int kk = 0; kk < 18; ++kk) {
+    const int tap = kk >> 1, half = kk & 1;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int qb = (wmr * 4 + kh) * PW + kw + lrow;      // patch pixel of tile row 4 wmr, this lane's column, this tap
+    gran_t af[2][2], bf[4][2];
+#define BN128_READ_A(i0_)                                                                                \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+    const int q = qb + ((i0_) + i) * PW;                                                                 \
+    const unsigned char* rowp = sT + half * PLANE + q * 128;                                             \
+    af[i][0] = *reinterpret_cast<const gran_t*>(rowp + ((lgrp ^ (q & 7)) << 4));                         \
+    af[i][1] = *reinterpret_cast<const gran_t*>(rowp + (((4 + lgrp) ^ (q & 7)) << 4));                   \
+  }
+#define BN128_MMA(i0_)                                                                                   \
+  {                                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
+          if constexpr (ABL & 2) { asm volatile("" ::"v"(af[i][ks]), "v"(bf[j][ks])); }                  \
+          else acc[(i0_) + i][j] = mma_granule<T>(af[i][ks], bf[j][ks], acc[(i0_) + i][j]);              \
+        }                                                                                                \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  }
+    // phase 1
+    BN128_READ_A(0)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf[j][0] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + fbn);
+      bf[j][1] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + (fbn ^ 64));
+    }
+    BN128_STAGE(0)
+    BN128_BARRIER()
+    BN128_MMA(0)
+    BN128_BARRIER()
+    // phase 2
+    BN128_READ_A(2)
+    BN128_STAGE(1)
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    BN128_BARRIER()
+    BN128_MMA(2)
+    BN128_BARRIER()
+    cb = cb == 2 ? 0 : cb + 1;
+  }
+#undef BN128_READ_A
+#undef BN128_MMA
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-page tiles staged past the last K tile
+  if (grp == 0) BN128_BARRIER()
+  BN128_BARRIER()                                     // nobody reads the t patch any more: the strips may overwrite it
+#undef BN128_STAGE
+#undef BN128_BARRIER
+
+  // ---- epilogue: bias + SiLU -> strip -> (+ shortcut) -> 16-bit rows; strip i = tile row 4 wmr + i, 16 pixels x 64 channels
+  if constexpr (ABL & 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+  float* stage = reinterpret_cast<float*>(sT) + wave * (16 * SLD);
+  float b2v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b2v[j] = p.b2 != nullptr ? p.b2[wnc * 64 + j * 16 + lrow] : 0.0f;
+  gran_t rs[4][2];
+  if (p.shortcut) {          // shortcut vectors of all four strips, requested up front (L2 hits: the patch was just read)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int it = lane + v * 64;
+        const int row = it >> 3, col = (it & 7) * 8;
+        const int x = x0 + row, y = y0 + wmr * 4 + i;
+        gran_t t = {0u, 0u, 0u, 0u};
+        if (x < p.W && y < p.H)
+          t = *reinterpret_cast<const gran_t*>(p.x + ((img_pix + (long)y * p.W + x) * p.ldx + p.xoff + wnc * 64 + col) * 2);
+        rs[i][v] = t;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        stage[(lgrp * 4 + e) * SLD + j * 16 + lrow] = apply_act<CFT_ACT_SILU>(acc[i][j][e] + b2v[j]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int it = lane + v * 64;
+      const int row = it >> 3, col = (it & 7) * 8;
+      const int x = x0 + row, y = y0 + wmr * 4 + i;
+      if (x < p.W && y < p.H) {
+        const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col);
+        const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col + 4);
+        float o[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        if (p.shortcut) {
+          float rf[8];
+          Elem<T>::unpack(rs[i][v], rf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += rf[e];
+        }
+        *reinterpret_cast<gran_t*>(p.y + ((img_pix + (long)y * p.W + x) * p.ldy + p.yoff + wnc * 64 + col) * 2) = Elem<T>::pack(o);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, int kpad1, const float* b1,
                               const void* w2, int kpad2, const float* b2, void* y, int ldy, int yoff,
                               int B, int H, int W, int c, int shortcut, int dtype, void* stream) {
   CFT_REQUIRE(x && w1 && w2 && y, "cft_bottleneck: null pointer");
   CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F16, "cft_bottleneck: dtype must be CFT_BF16 or CFT_F16");
-  CFT_REQUIRE(c == 64, "cft_bottleneck: the fused kernel covers 64 channels (use two cft_conv2d calls otherwise)");
+  CFT_REQUIRE(c == 64 || c == 128, "cft_bottleneck: the fused kernels cover 64 and 128 channels (use two cft_conv2d calls otherwise)");
   CFT_REQUIRE(B > 0 && H > 0 && W > 0, "cft_bottleneck: non-positive size");
   CFT_REQUIRE(kpad1 >= c && kpad1 % 64 == 0 && kpad2 >= 9 * c && kpad2 % 64 == 0, "cft_bottleneck: weights must be packed as for cft_conv2d");
   CFT_REQUIRE(ldx % 8 == 0 && xoff % 8 == 0 && ldy % 8 == 0 && yoff % 8 == 0 && ldx >= xoff + c && ldy >= yoff + c,
@@ -246,6 +525,35 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
     const bool disjoint_mem = ya + ybytes <= xa || xa + xbytes <= ya;
     const bool disjoint_slice = ldx == ldy && d >= (long)c * 2 && d + (long)c * 2 <= (long)ldx * 2;   // same pixel grid, other channels
     CFT_REQUIRE(disjoint_mem || disjoint_slice, "cft_bottleneck: output overlaps the input (halo reads forbid in-place)");
+  }
+  if (c == 128) {
+    Bneck128Params q;
+    q.x = (const unsigned char*)x; q.w1 = (const unsigned char*)w1; q.w2 = (const unsigned char*)w2;
+    q.b1 = b1; q.b2 = b2; q.y = (unsigned char*)y;
+    q.ldx = ldx; q.xoff = xoff; q.ldy = ldy; q.yoff = yoff; q.kpad1 = kpad1; q.kpad2 = kpad2;
+    q.H = H; q.W = W; q.tiles_x = (W + 15) / 16; q.tiles_y = (H + 15) / 16; q.shortcut = shortcut ? 1 : 0;
+    CFT_REQUIRE((long)B * q.tiles_x * q.tiles_y < (1L << 31), "cft_bottleneck: too many tiles");
+    constexpr int smem128 = 2 * 21 * 16 * 128 + 3 * 16384;
+    const dim3 grid128(B * q.tiles_x * q.tiles_y), block128(512);
+    hipStream_t s128 = as_stream(stream);
+#define BN128_LAUNCH(T_, ABL_)                                                                    \
+    {                                                                                             \
+      cft_allow_lds<&bottleneck128_kernel<T_, ABL_>>(smem128);                                    \
+      hipLaunchKernelGGL((bottleneck128_kernel<T_, ABL_>), grid128, block128, smem128, s128, q);  \
+    }
+    if (dtype == CFT_F16) {
+      BN128_LAUNCH(f16_t, 0)
+    } else {
+      switch (g_conv_variant) {   // timing probes: 1 = no t-patch MFMAs, 2 = no 3x3 MFMAs, 4 = no epilogue, 8 = no weight DMA
+        case 901: BN128_LAUNCH(uint16_t, 1) break;
+        case 902: BN128_LAUNCH(uint16_t, 2) break;
+        case 904: BN128_LAUNCH(uint16_t, 4) break;
+        case 908: BN128_LAUNCH(uint16_t, 8) break;
+        default: BN128_LAUNCH(uint16_t, 0) break;
+      }
+    }
+#undef BN128_LAUNCH
+    return cft_check_launch("bottleneck128_kernel");
   }
   BneckParams p;
   p.x = (const unsigned char*)x; p.w1 = (const unsigned char*)w1; p.w2 = (const unsigned char*)w2;

@@ -811,11 +811,14 @@ static int launch_conv8n(const ConvParams& p, hipStream_t stream) {
   }
 }
 
-// The staggered-group kernels replace the 16-wave 256x256 / 8-wave 192x128 tiles in the automatic choice for 16-bit
-// operands; CFT_AUTO8=0 in the environment restores the previous choice (A/B runs).
+// The staggered-group kernels are bit-identical to the lock-step ones but measured SLOWER on MI355X when both operands
+// stream through the LDS-DMA path (profiles/r02_gemm_experiments.md: their MFMA-only loop runs at 1.6 PFLOP/s, but the
+// L2 -> LDS request stream, 64 KiB per K tile per CU, needs 1.18 us per tile against 1.01 us of MFMA work and does
+// not overlap well across the 8 barriers per tile).  They stay selectable (variants 80 / 81, or CFT_AUTO8=1 in the
+// environment to put them into the automatic choice for A/B runs); the default choice is unchanged.
 static bool auto8_enabled() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("CFT_AUTO8"); v = (e && e[0] == '0') ? 0 : 1; }
+  if (v < 0) { const char* e = getenv("CFT_AUTO8"); v = (e && e[0] == '1') ? 1 : 0; }
   return v == 1;
 }
 

@@ -9,32 +9,101 @@
 //            score in LDS, then everything below it is dropped (candidates that TIE with that score all stay;
 //            the reference's unstable argsort leaves their order unspecified);
 //   phase 2  greedy selection: up to max_det rounds of {workgroup arg-max of the live scores, emit it,
-//            kill every live box whose IoU with it exceeds iou_thres}.  Boxes of different classes are
-//            separated by the reference's class offset (cls * 4096) unless agnostic.  This is exactly the
-//            order torchvision's nms produces (descending score) truncated to max_det, without sorting
-//            all candidates: the work is O(max_det * n / 1024) per image.
+//            kill every live box whose IoU with it exceeds iou_thres}, run on LDS-resident CHUNKS of the
+//            highest remaining scores (see nms_kernel).  Boxes of different classes are separated by the
+//            reference's class offset (cls * 4096) unless agnostic.  This is exactly the order torchvision's
+//            nms produces (descending score) truncated to max_det, without sorting all candidates.
 // Ties between equal scores are broken by the lower (row, class) key, which makes the result deterministic.
 #include "cft_common.h"
 
-struct NmsCand { float x1, y1, x2, y2, score; int cls; int key; int pad; };   // 32 bytes
+// Scratch layout per image (structure of arrays, cap = rows * (multi_label ? nc : 1) entries, 32 bytes per entry):
+//   score[cap] float | box[cap] float4 (x1,y1,x2,y2) | cls[cap] int | key[cap] int
+struct NmsView {
+  float* score;
+  float4* box;
+  int* cls;
+  int* key;
+};
+__device__ __forceinline__ NmsView nms_view(unsigned char* base, long cap) {
+  NmsView v;
+  v.score = reinterpret_cast<float*>(base);
+  v.box = reinterpret_cast<float4*>(base + cap * 4);
+  v.cls = reinterpret_cast<int*>(base + cap * 20);
+  v.key = reinterpret_cast<int*>(base + cap * 24);
+  return v;
+}
 
 __device__ __forceinline__ bool better(float s, int k, float s2, int k2) { return s > s2 || (s == s2 && k < k2); }
 
+__device__ __forceinline__ bool iou_exceeds(float x1, float y1, float x2, float y2, float bx1, float by1, float bx2, float by2, float thr) {
+  const float iw = fminf(x2, bx2) - fmaxf(x1, bx1), ih = fminf(y2, by2) - fmaxf(y1, by1);
+  const float inter = (iw > 0.f ? iw : 0.f) * (ih > 0.f ? ih : 0.f);
+  const float iou = inter / ((x2 - x1) * (y2 - y1) + (bx2 - bx1) * (by2 - by1) - inter);
+  return iou > thr;
+}
+
+constexpr int NMS_CHUNK = 2048;       // candidates resident in LDS per chunk
+constexpr int NMS_MAXDET_LDS = 1024;  // kept boxes remembered in LDS (max_det above this uses the global-memory path)
+
+// Workgroup-wide radix select over the positive scores with bit pattern < hi: returns (through s_prefix) the bit pattern
+// of the want-th largest of them (want >= 1; there must be at least `want`).  Four 8-bit passes, LDS histogram.
+__device__ __forceinline__ unsigned nms_radix_select(const float* __restrict__ score, int n, unsigned hi, unsigned want,
+                                                     unsigned* s_hist, unsigned* s_prefix, unsigned* s_want, int tid) {
+  if (tid == 0) { *s_prefix = 0u; *s_want = want; }
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (tid < 256) s_hist[tid] = 0u;
+    __syncthreads();
+    const unsigned prefix = *s_prefix;
+    const unsigned hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+    for (int i = tid; i < n; i += 1024) {
+      const float sc = score[i];
+      const unsigned u = __float_as_uint(sc);
+      if (sc > 0.f && u < hi && (u & hi_mask) == prefix) atomicAdd(&s_hist[(u >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned w = *s_want, d = 255u;
+      for (;; --d) {
+        if (s_hist[d] >= w || d == 0u) break;
+        w -= s_hist[d];
+      }
+      *s_want = w;
+      *s_prefix = prefix | (d << shift);
+    }
+    __syncthreads();
+  }
+  return *s_prefix;
+}
+
+// One 1024-thread workgroup per image.
+//   phase 1   candidate filter + compaction into the image's scratch (see the file header);
+//   phase 1b  max_nms pre-truncation (radix select of the max_nms-th score);
+//   phase 2   greedy selection in CHUNKS of the highest remaining scores: the next <= 2048 candidates by score are
+//             copied into LDS (a radix select finds the chunk's score threshold; candidates that tie with it all
+//             belong to the chunk), first thinned by the boxes kept so far, then up to max_det rounds of
+//             {workgroup arg-max of the live scores, emit, kill what it suppresses} run entirely on LDS.  Greedy NMS
+//             visits candidates in descending score, so nothing outside the current chunk can precede anything in it;
+//             with max_det = 300 the first chunk almost always suffices and the 25200-row arrays are only read twice.
+//             (A chunk whose score ties overflow the LDS arrays falls back to rounds over global memory.)
 __global__ void __launch_bounds__(1024) nms_kernel(const float* __restrict__ pred, int rows, int no, float conf_thres,
                                                    float iou_thres, int agnostic, int multi_label, const unsigned char* __restrict__ class_allow,
-                                                   int max_det, int max_nms, int cap, NmsCand* __restrict__ scratch, float* __restrict__ dets,
+                                                   int max_det, int max_nms, int cap, unsigned char* __restrict__ scratch, float* __restrict__ dets,
                                                    int* __restrict__ counts) {
-  __shared__ int s_n;
+  __shared__ int s_n, s_m, s_best;
   __shared__ unsigned s_hist[256];
   __shared__ unsigned s_prefix, s_want;
   __shared__ float s_score[16];
   __shared__ int s_key[16], s_idx[16];
   __shared__ float s_box[4];
-  __shared__ int s_best;
+  __shared__ float c_x1[NMS_CHUNK], c_y1[NMS_CHUNK], c_x2[NMS_CHUNK], c_y2[NMS_CHUNK], c_sc[NMS_CHUNK];
+  __shared__ int c_idx[NMS_CHUNK], c_key[NMS_CHUNK];   // c_x1.. hold the class-shifted boxes the IoU runs on; c_idx -> the exact box
+  __shared__ float k_x1[NMS_MAXDET_LDS], k_y1[NMS_MAXDET_LDS], k_x2[NMS_MAXDET_LDS], k_y2[NMS_MAXDET_LDS];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nc = no - 5;
   const float* P = pred + (long)b * rows * no;
-  NmsCand* C = scratch + (long)b * cap;
+  const long cap_al = ((long)cap + 3) & ~3L;     // keeps the float4 box array 16-byte aligned
+  const NmsView C = nms_view(scratch + (long)b * cap_al * 32, cap_al);
+  const float max_wh = 4096.f;
   if (tid == 0) s_n = 0;
   __syncthreads();
   // ---- phase 1 ----
@@ -48,7 +117,7 @@ __global__ void __launch_bounds__(1024) nms_kernel(const float* __restrict__ pre
         const float conf = p[5 + c] * obj;
         if (conf > conf_thres && (class_allow == nullptr || class_allow[c])) {
           const int i = atomicAdd(&s_n, 1);
-          if (i < cap) C[i] = NmsCand{cx - hw, cy - hh, cx + hw, cy + hh, conf, c, r * nc + c, 0};
+          if (i < cap) { C.score[i] = conf; C.box[i] = make_float4(cx - hw, cy - hh, cx + hw, cy + hh); C.cls[i] = c; C.key[i] = r * nc + c; }
         }
       }
     } else {
@@ -60,94 +129,197 @@ __global__ void __launch_bounds__(1024) nms_kernel(const float* __restrict__ pre
       }
       if (best > conf_thres && (class_allow == nullptr || class_allow[bc])) {
         const int i = atomicAdd(&s_n, 1);
-        if (i < cap) C[i] = NmsCand{cx - hw, cy - hh, cx + hw, cy + hh, best, bc, r, 0};
+        if (i < cap) { C.score[i] = best; C.box[i] = make_float4(cx - hw, cy - hh, cx + hw, cy + hh); C.cls[i] = bc; C.key[i] = r; }
       }
     }
   }
   __syncthreads();
   const int n = s_n < cap ? s_n : cap;
   __threadfence_block();
-  // ---- phase 1b: keep only the max_nms best scores (scores are positive floats: their bit patterns order like uints)
+  // ---- phase 1b: keep only the max_nms best scores (positive floats order like their bit patterns) ----
   if (max_nms > 0 && n > max_nms) {
-    if (tid == 0) { s_prefix = 0u; s_want = (unsigned)max_nms; }
-    for (int shift = 24; shift >= 0; shift -= 8) {
-      if (tid < 256) s_hist[tid] = 0u;
-      __syncthreads();
-      const unsigned prefix = s_prefix;
-      const unsigned hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
-      for (int i = tid; i < n; i += 1024) {
-        const unsigned u = __float_as_uint(C[i].score);
-        if ((u & hi_mask) == prefix) atomicAdd(&s_hist[(u >> shift) & 255u], 1u);
-      }
-      __syncthreads();
-      if (tid == 0) {   // walk the digits from the top: the bucket in which the want-th largest score falls
-        unsigned want = s_want, d = 255u;
-        for (;; --d) {
-          if (s_hist[d] >= want || d == 0u) break;
-          want -= s_hist[d];
-        }
-        s_want = want;
-        s_prefix = prefix | (d << shift);
-      }
-      __syncthreads();
-    }
-    const unsigned kth = s_prefix;     // bit pattern of the max_nms-th largest score
+    const unsigned kth = nms_radix_select(C.score, n, 0xffffffffu, (unsigned)max_nms, s_hist, &s_prefix, &s_want, tid);
     for (int i = tid; i < n; i += 1024)
-      if (__float_as_uint(C[i].score) < kth) C[i].score = -1.f;
+      if (__float_as_uint(C.score[i]) < kth) C.score[i] = -1.f;
     __syncthreads();
     __threadfence_block();
   }
   // ---- phase 2 ----
-  const float max_wh = 4096.f;
   int kept = 0;
-  float bx1 = 0.f, by1 = 0.f, bx2 = 0.f, by2 = 0.f;
-  bool have_best = false;
-  for (int round = 0; round <= max_det; ++round) {
-    // one sweep: kill what the previous winner suppresses, find this thread's best live candidate
-    float ls = -1.f;
-    int lk = 0x7fffffff, li = -1;
+  unsigned hi = 0xffffffffu;          // candidates with score bits >= hi are done (selected, suppressed or earlier chunks)
+  const bool kept_in_lds = max_det <= NMS_MAXDET_LDS;
+  while (kept < max_det) {
+    // remaining live candidates below hi
+    if (tid == 0) s_m = 0;
+    __syncthreads();
+    int cnt = 0;
     for (int i = tid; i < n; i += 1024) {
-      NmsCand c = C[i];
-      if (c.score < 0.f) continue;
-      if (have_best) {
-        const float off = agnostic ? 0.f : (float)c.cls * max_wh;
-        const float x1 = c.x1 + off, y1 = c.y1 + off, x2 = c.x2 + off, y2 = c.y2 + off;
-        const float iw = fminf(x2, bx2) - fmaxf(x1, bx1), ih = fminf(y2, by2) - fmaxf(y1, by1);
-        const float inter = (iw > 0.f ? iw : 0.f) * (ih > 0.f ? ih : 0.f);
-        const float iou = inter / ((x2 - x1) * (y2 - y1) + (bx2 - bx1) * (by2 - by1) - inter);
-        if (iou > iou_thres) { C[i].score = -1.f; continue; }
-      }
-      if (better(c.score, c.key, ls, lk)) { ls = c.score; lk = c.key; li = i; }
+      const float sc = C.score[i];
+      cnt += (sc > 0.f && __float_as_uint(sc) < hi) ? 1 : 0;
     }
-    if (round == max_det) break;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float s2 = __shfl_xor(ls, o);
-      const int k2 = __shfl_xor(lk, o), i2 = __shfl_xor(li, o);
-      if (better(s2, k2, ls, lk)) { ls = s2; lk = k2; li = i2; }
-    }
-    if (lane == 0) { s_score[wave] = ls; s_key[wave] = lk; s_idx[wave] = li; }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0 && cnt) atomicAdd(&s_m, cnt);
     __syncthreads();
-    if (tid == 0) {
-      float bs = s_score[0]; int bk = s_key[0], bi = s_idx[0];
-      for (int w = 1; w < 16; ++w)
-        if (better(s_score[w], s_key[w], bs, bk)) { bs = s_score[w]; bk = s_key[w]; bi = s_idx[w]; }
-      s_best = bi;
-      if (bi >= 0) {
-        const NmsCand c = C[bi];
-        float* d = dets + ((long)b * max_det + kept) * 6;
-        d[0] = c.x1; d[1] = c.y1; d[2] = c.x2; d[3] = c.y2; d[4] = c.score; d[5] = (float)c.cls;
-        const float off = agnostic ? 0.f : (float)c.cls * max_wh;
-        s_box[0] = c.x1 + off; s_box[1] = c.y1 + off; s_box[2] = c.x2 + off; s_box[3] = c.y2 + off;
-        C[bi].score = -1.f;   // the winner suppresses itself
+    const int rem = s_m;
+    if (rem == 0) break;
+    unsigned thr = 0u;                // chunk = live candidates with thr <= bits < hi
+    int m = rem;
+    if (rem > NMS_CHUNK) {
+      thr = nms_radix_select(C.score, n, hi, (unsigned)(NMS_CHUNK / 2), s_hist, &s_prefix, &s_want, tid);
+      if (tid == 0) s_m = 0;
+      __syncthreads();
+      cnt = 0;
+      for (int i = tid; i < n; i += 1024) {
+        const float sc = C.score[i];
+        const unsigned u = __float_as_uint(sc);
+        cnt += (sc > 0.f && u < hi && u >= thr) ? 1 : 0;
       }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+      if (lane == 0 && cnt) atomicAdd(&s_m, cnt);
+      __syncthreads();
+      m = s_m;
     }
-    __syncthreads();
-    if (s_best < 0) break;
-    bx1 = s_box[0]; by1 = s_box[1]; bx2 = s_box[2]; by2 = s_box[3];
-    have_best = true;
-    ++kept;
-    __syncthreads();   // s_box / s_best are rewritten next round; winner's score store is visible to all
+    const bool in_lds = m <= NMS_CHUNK && kept_in_lds;    // uniform
+    if (in_lds) {
+      // gather the chunk into LDS (order irrelevant: the arg-max breaks ties by key)
+      __syncthreads();
+      if (tid == 0) s_m = 0;
+      __syncthreads();
+      for (int i = tid; i < n; i += 1024) {
+        const float sc = C.score[i];
+        const unsigned u = __float_as_uint(sc);
+        if (sc > 0.f && u < hi && u >= thr) {
+          const int j = atomicAdd(&s_m, 1);
+          const float4 bx = C.box[i];
+          const int cl = C.cls[i];
+          const float off = agnostic ? 0.f : (float)cl * max_wh;
+          c_x1[j] = bx.x + off; c_y1[j] = bx.y + off; c_x2[j] = bx.z + off; c_y2[j] = bx.w + off;
+          c_sc[j] = sc; c_idx[j] = i; c_key[j] = C.key[i];
+        }
+      }
+      __syncthreads();
+      // thin by the boxes kept so far (earlier chunks)
+      if (kept > 0) {
+        for (int j = tid; j < m; j += 1024) {
+          const float x1 = c_x1[j], y1 = c_y1[j], x2 = c_x2[j], y2 = c_y2[j];
+          bool dead = false;
+          for (int k = 0; k < kept && !dead; ++k) dead = iou_exceeds(x1, y1, x2, y2, k_x1[k], k_y1[k], k_x2[k], k_y2[k], iou_thres);
+          if (dead) c_sc[j] = -1.f;
+        }
+        __syncthreads();
+      }
+      // greedy rounds on the LDS chunk
+      float bx1 = 0.f, by1 = 0.f, bx2 = 0.f, by2 = 0.f;
+      bool have_best = false;
+      for (;;) {
+        float ls = -1.f;
+        int lk = 0x7fffffff, li = -1;
+        for (int j = tid; j < m; j += 1024) {
+          const float sc = c_sc[j];
+          if (sc < 0.f) continue;
+          if (have_best && iou_exceeds(c_x1[j], c_y1[j], c_x2[j], c_y2[j], bx1, by1, bx2, by2, iou_thres)) { c_sc[j] = -1.f; continue; }
+          const int ky = c_key[j];
+          if (better(sc, ky, ls, lk)) { ls = sc; lk = ky; li = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float s2 = __shfl_xor(ls, o);
+          const int k2 = __shfl_xor(lk, o), i2 = __shfl_xor(li, o);
+          if (better(s2, k2, ls, lk)) { ls = s2; lk = k2; li = i2; }
+        }
+        if (lane == 0) { s_score[wave] = ls; s_key[wave] = lk; s_idx[wave] = li; }
+        __syncthreads();
+        if (tid == 0) {
+          float bs = s_score[0]; int bk = s_key[0], bi = s_idx[0];
+          for (int w = 1; w < 16; ++w)
+            if (better(s_score[w], s_key[w], bs, bk)) { bs = s_score[w]; bk = s_key[w]; bi = s_idx[w]; }
+          s_best = bi;
+          if (bi >= 0) {
+            const float4 ex = C.box[c_idx[bi]];      // the unshifted box, bit-exact (the reference returns x[i], not boxes[i])
+            float* d = dets + ((long)b * max_det + kept) * 6;
+            d[0] = ex.x; d[1] = ex.y; d[2] = ex.z; d[3] = ex.w; d[4] = bs; d[5] = (float)C.cls[c_idx[bi]];
+            s_box[0] = c_x1[bi]; s_box[1] = c_y1[bi]; s_box[2] = c_x2[bi]; s_box[3] = c_y2[bi];
+            k_x1[kept] = c_x1[bi]; k_y1[kept] = c_y1[bi]; k_x2[kept] = c_x2[bi]; k_y2[kept] = c_y2[bi];
+            c_sc[bi] = -1.f;
+          }
+        }
+        __syncthreads();
+        if (s_best < 0) break;            // chunk exhausted
+        bx1 = s_box[0]; by1 = s_box[1]; bx2 = s_box[2]; by2 = s_box[3];
+        have_best = true;
+        ++kept;
+        if (kept == max_det) break;
+        __syncthreads();                  // s_box / s_best are rewritten next round
+      }
+      __syncthreads();
+      if (thr == 0u) break;               // that was everything
+      hi = thr;
+    } else {
+      // fallback (score ties overflow the LDS chunk, or max_det beyond the LDS kept list): rounds over global memory
+      // on everything that is still live; the boxes kept so far suppress through the first sweep
+      for (int i = tid; i < n; i += 1024) {
+        const float sc = C.score[i];
+        if (!(sc > 0.f) || !(__float_as_uint(sc) < hi)) { if (sc > 0.f) C.score[i] = -1.f; continue; }
+        if (kept_in_lds && kept > 0) {
+          const float4 bx = C.box[i];
+          const float off = agnostic ? 0.f : (float)C.cls[i] * max_wh;
+          bool dead = false;
+          for (int k = 0; k < kept && !dead; ++k) dead = iou_exceeds(bx.x + off, bx.y + off, bx.z + off, bx.w + off, k_x1[k], k_y1[k], k_x2[k], k_y2[k], iou_thres);
+          if (dead) C.score[i] = -1.f;
+        }
+      }
+      __syncthreads();
+      __threadfence_block();
+      float bx1 = 0.f, by1 = 0.f, bx2 = 0.f, by2 = 0.f;
+      bool have_best = false;
+      for (;;) {
+        float ls = -1.f;
+        int lk = 0x7fffffff, li = -1;
+        for (int i = tid; i < n; i += 1024) {
+          const float sc = C.score[i];
+          if (sc < 0.f) continue;
+          const float4 bx = C.box[i];
+          const float off = agnostic ? 0.f : (float)C.cls[i] * max_wh;
+          if (have_best && iou_exceeds(bx.x + off, bx.y + off, bx.z + off, bx.w + off, bx1, by1, bx2, by2, iou_thres)) { C.score[i] = -1.f; continue; }
+          const int ky = C.key[i];
+          if (better(sc, ky, ls, lk)) { ls = sc; lk = ky; li = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float s2 = __shfl_xor(ls, o);
+          const int k2 = __shfl_xor(lk, o), i2 = __shfl_xor(li, o);
+          if (better(s2, k2, ls, lk)) { ls = s2; lk = k2; li = i2; }
+        }
+        if (lane == 0) { s_score[wave] = ls; s_key[wave] = lk; s_idx[wave] = li; }
+        __syncthreads();
+        if (tid == 0) {
+          float bs = s_score[0]; int bk = s_key[0], bi = s_idx[0];
+          for (int w = 1; w < 16; ++w)
+            if (better(s_score[w], s_key[w], bs, bk)) { bs = s_score[w]; bk = s_key[w]; bi = s_idx[w]; }
+          s_best = bi;
+          if (bi >= 0) {
+            const float4 bx = C.box[bi];
+            const int cl = C.cls[bi];
+            float* d = dets + ((long)b * max_det + kept) * 6;
+            d[0] = bx.x; d[1] = bx.y; d[2] = bx.z; d[3] = bx.w; d[4] = bs; d[5] = (float)cl;
+            const float off = agnostic ? 0.f : (float)cl * max_wh;
+            s_box[0] = bx.x + off; s_box[1] = bx.y + off; s_box[2] = bx.z + off; s_box[3] = bx.w + off;
+            C.score[bi] = -1.f;
+          }
+        }
+        __syncthreads();
+        if (s_best < 0) break;
+        bx1 = s_box[0]; by1 = s_box[1]; bx2 = s_box[2]; by2 = s_box[3];
+        have_best = true;
+        ++kept;
+        if (kept == max_det) break;
+        __syncthreads();
+        __threadfence_block();
+      }
+      break;                               // the fallback consumed every remaining candidate
+    }
   }
   if (tid == 0) counts[b] = kept;
 }
@@ -159,8 +331,10 @@ extern "C" int cft_nms(const float* pred, int B, int rows, int no, float conf_th
   CFT_REQUIRE(B > 0 && rows > 0 && no >= 6 && max_det > 0 && max_nms >= 0, "cft_nms: bad shape (needs at least one class)");
   const int nc = no - 5;
   const long cap = (long)rows * (multi_label ? nc : 1);
-  CFT_REQUIRE(cap < (1L << 30) && scratch_bytes >= (long)B * cap * (long)sizeof(NmsCand), "cft_nms: scratch too small (need B*rows*(multi_label?nc:1)*32 bytes)");
+  const long cap_al = (cap + 3) & ~3L;
+  CFT_REQUIRE(cap < (1L << 30) && scratch_bytes >= (long)B * cap_al * 32L, "cft_nms: scratch too small (need B * round_up(rows*(multi_label?nc:1), 4) * 32 bytes)");
+  CFT_REQUIRE(((size_t)scratch & 15) == 0, "cft_nms: scratch must be 16-byte aligned");
   hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), 0, as_stream(stream), pred, rows, no, conf_thres, iou_thres, agnostic, multi_label,
-                     class_allow, max_det, max_nms, (int)cap, (NmsCand*)scratch, dets, counts);
+                     class_allow, max_det, max_nms, (int)cap, (unsigned char*)scratch, dets, counts);
   return cft_check_launch("nms_kernel");
 }

@@ -306,14 +306,14 @@ __global__ void __launch_bounds__(256) to_nhwc_kernel(const unsigned char* __res
 }
 
 extern "C" int cft_to_nhwc(const void* in, int in_dtype, long stride_b, long stride_c, long stride_h, long stride_w,
-                           void* out, int ldo, int ooff, int B, int C, int H, int W, int dtype, void* stream) {
+                           void* out, int ldo, int ooff, int B, int C, int cpad, int H, int W, int dtype, void* stream) {
   CFT_REQUIRE(in && out, "cft_to_nhwc: null pointer");
   CFT_REQUIRE(cft_is_dtype(in_dtype) && cft_is_dtype(dtype), "cft_to_nhwc: bad dtype");
   CFT_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "cft_to_nhwc: non-positive size");
   const int ge = cft_granule(dtype), es = cft_elem_size(dtype);
-  CFT_REQUIRE(ldo % ge == 0 && ooff % ge == 0 && ldo >= ooff + C, "cft_to_nhwc: output ld/offset not granule aligned or too small");
-  const int gpp = (C + ge - 1) / ge;
-  CFT_REQUIRE(ooff + gpp * ge <= ldo, "cft_to_nhwc: padded channel count exceeds ld");
+  CFT_REQUIRE(cpad >= C && cpad % ge == 0, "cft_to_nhwc: cpad must be >= C and a granule multiple");
+  CFT_REQUIRE(ldo % ge == 0 && ooff % ge == 0 && ldo >= ooff + cpad, "cft_to_nhwc: output ld/offset not granule aligned or too small");
+  const int gpp = cpad / ge;
   const long total = (long)B * H * W * gpp;
   const int grid = grid_for(total, 256);
   CFT_DISPATCH_DTYPE(in_dtype, TI, CFT_DISPATCH_DTYPE(dtype, TO,

@@ -253,7 +253,8 @@ class Focus(_Packed):
     then Conv.  Takes the fp32 image batch [B,3,H,W] (NCHW) and emits NHWC activations in
     ``compute_dtype`` - this module is where the compute precision of the whole network is set."""
 
-    compute_dtype = torch.bfloat16
+    compute_dtype = None   # None: the precision of the parameters (fp32 -> exact fp32 path, .half() -> fp16), like torch;
+                           # Model.set_compute_dtype() sets it explicitly (its default is bf16)
 
     def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
         super().__init__()
@@ -266,7 +267,8 @@ class Focus(_Packed):
 
     def forward(self, x):
         x = resolve(x)
-        return ops.focus_conv(x, self._packed(self.compute_dtype, x.device), _act_code(self.conv.act), self.compute_dtype)
+        dtype = self.compute_dtype or self.conv.conv.weight.dtype
+        return ops.focus_conv(x, self._packed(dtype, x.device), _act_code(self.conv.act), dtype)
 
 
 class Upsample(nn.Upsample):
@@ -481,3 +483,29 @@ class GPT(_Packed):
             blk(t2, dtype)
         tok_f = ops.layernorm(t2, lnf_w, lnf_b, torch.float32, self.ln_f.eps).view(B, 128, C)
         return PendingBilinear(tok_f, 0, H, W, dtype), PendingBilinear(tok_f, 1, H, W, dtype)
+
+
+# ------------------------------------------------------------------------------ names outside the hot path
+# The reference's graph file does ``from models.common import *`` and names these classes in its parse_model
+# membership tests (models/yolo_test.py:496-531), so they must EXIST for that file to run over this module
+# (strict form); no CFT / two-stream yaml instantiates them (SURVEY.md 2, rows marked OUT).
+def _outside(name, where):
+    def __init__(self, *a, **k):
+        raise NotImplementedError(f"{name} (reference {where}) is outside the two-stream CFT hot path; "
+                                  "no fusion yaml uses it (SURVEY.md section 2)")
+    return type(name, (nn.Module,), {"__init__": __init__, "__doc__": f"Placeholder for the reference's {name} ({where})."})
+
+
+def DWConv(c1, c2, k=1, s=1, act=True):  # reference models/common.py:31-33 (depthwise: grouped conv, not in any CFT yaml)
+    raise NotImplementedError("DWConv (grouped convolution) is outside the two-stream CFT hot path")
+
+
+TransformerLayer = _outside("TransformerLayer", "models/common.py:53-67")
+TransformerBlock = _outside("TransformerBlock", "models/common.py:70-96")
+BottleneckCSP = _outside("BottleneckCSP", "models/common.py:112-128")
+C3TR = _outside("C3TR", "models/common.py:146-151")
+Contract = _outside("Contract", "models/common.py:183-194")
+Expand = _outside("Expand", "models/common.py:197-208")
+NMS = _outside("NMS", "models/common.py:247-257")
+autoShape = _outside("autoShape", "models/common.py:260-327")
+Classify = _outside("Classify", "models/common.py:417-427")

@@ -58,7 +58,7 @@ def to_nhwc(x, dtype=None, cpad=None):
     cp = cpad or ((C + ge - 1) // ge) * ge
     y = new_nhwc(B, H, W, cp, dtype, x.device)
     st = _lib.load().cft_to_nhwc(x.data_ptr(), _dt(x.dtype), x.stride(0), x.stride(1), x.stride(2), x.stride(3),
-                                 y.data_ptr(), cp, 0, B, C, H, W, _dt(dtype), _stream())
+                                 y.data_ptr(), cp, 0, B, C, cp, H, W, _dt(dtype), _stream())
     _lib.check(st, "cft_to_nhwc")
     return y
 
@@ -204,15 +204,18 @@ def conv2d(x, pk, act, residual=None, out=None, out_dtype=None):
     return out
 
 
+FUSED_BOTTLENECK_WIDTHS = (64, 128)   # cft_bottleneck: 64 (3x3 weights LDS-resident), 128 (activation patch resident, weights streamed)
+
+
 def bottleneck_fusable(x, pk1, pk2, act1, act2):
     """True when ``bottleneck`` below can run as the single cft_bottleneck kernel."""
     return (x.dtype in (torch.bfloat16, torch.float16) and act1 == ACT_SILU and act2 == ACT_SILU
             and pk1.k == 1 and pk1.s == 1 and pk2.k == 3 and pk2.s == 1
-            and pk1.cin == pk1.n == pk2.cin == pk2.n == 64 and x.shape[1] == 64)
+            and pk1.cin == pk1.n == pk2.cin == pk2.n == x.shape[1] and x.shape[1] in FUSED_BOTTLENECK_WIDTHS)
 
 
 def bottleneck(x, pk1, pk2, shortcut, out=None):
-    """x (+) SiLU(conv3x3(SiLU(conv1x1(x)))) for 64 channels in one kernel (cft_bottleneck); ``out`` must not
+    """x (+) SiLU(conv3x3(SiLU(conv1x1(x)))) for 64 / 128 channels in one kernel (cft_bottleneck); ``out`` must not
     overlap ``x`` (a disjoint channel slice of the same buffer is fine)."""
     _require_cuda(x, "bottleneck")
     x, ldx = as_nhwc(x)
@@ -288,7 +291,7 @@ def focus_s2d(img, dtype):
             raise ValueError("focus_s2d: non-fp32 / strided images need uniform batch/channel strides and W % 4 == 0")
         flat = torch.empty((B, 3, H, W), dtype=torch.float32, device=img.device)
         st = _lib.load().cft_to_nhwc(img.data_ptr(), _dt(img.dtype), img.stride(1), img.stride(3), img.stride(2), 0,
-                                     flat.data_ptr(), W, 0, B * 3, W, H, 1, CFT_F32, _stream())
+                                     flat.data_ptr(), W, 0, B * 3, W, W, H, 1, CFT_F32, _stream())
         _lib.check(st, "cft_to_nhwc(image)")
         img = flat
     out = new_nhwc(B, H // 2, W // 2, 16, dtype, img.device)

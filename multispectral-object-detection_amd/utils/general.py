@@ -34,7 +34,7 @@ def batched_nms(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnos
     nc = no - 5
     multi_label = bool(multi_label) and nc > 1            # reference :472
     cap = rows * (nc if multi_label else 1)
-    scratch = torch.empty((B * cap * 32,), dtype=torch.uint8, device=prediction.device)
+    scratch = torch.empty((B * ((cap + 3) // 4 * 4) * 32,), dtype=torch.uint8, device=prediction.device)
     dets = torch.zeros((B, max_det, 6), dtype=torch.float32, device=prediction.device)
     counts = torch.zeros((B,), dtype=torch.int32, device=prediction.device)
     allow = classes if isinstance(classes, torch.Tensor) and classes.dtype == torch.uint8 else _class_table(classes, nc, prediction.device)

@@ -114,8 +114,8 @@ def make_nms_golden():
 
 def make_checkpoint():
     """A checkpoint exactly as the reference's train.py:850-860 writes one - the whole ``nn.Module`` pickled,
-    ``.half()``, inside a dict with ``ema`` - for a deliberately tiny two-stream CFTx3 network (width 0.0625:
-    8..64 channels, GPT widths 16/32/64, i.e. head widths 2/4/8 that the attention kernel zero-pads).
+    ``.half()``, inside a dict with ``ema`` - for a deliberately tiny two-stream CFTx3 network (width 0.125:
+    8..128 channels (hidden C3 widths down to 8, the smallest the 16-byte-granule kernels take), GPT widths 32/64/128, i.e. head widths 4/8/16 that the attention kernel zero-pads).
     ``ref_ckpt_tiny.pt`` holds nothing but what the reference's own classes pickle; ``ref_ckpt_tiny_out.pt`` holds
     the reference's outputs for it (after ``attempt_load``'s ``.float().fuse().eval()``,
     models/experimental.py:119) on seeded inputs.  The GPU box has no /root/reference: the -m gpu test
@@ -128,7 +128,7 @@ def make_checkpoint():
     from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict
     from models.yolo_test import Model  # the reference
     cfg = copy.deepcopy(named_config("yolov5s_fusion_transformerx3_vedai"))
-    cfg["width_multiple"], cfg["nc"] = 0.0625, 3
+    cfg["width_multiple"], cfg["nc"] = 0.125, 3
     torch.manual_seed(0)
     model = Model(cfg).eval()
     model.load_state_dict(seeded_state_dict(model.state_dict(), 9))

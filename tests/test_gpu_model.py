@@ -364,3 +364,53 @@ def test_yolov5x_four_cft_blocks_matches_oracle(dev):
     _check_f16(pred16, raw16, want_pred, want_raw)
     predb, rawb = _run(model, rgb, ir, dev, torch.bfloat16)
     _check_bf16(predb, rawb, want_pred, want_raw)
+
+
+def test_modules_under_a_foreign_executor_with_torch_neighbours(dev):
+    """The strict form of the boundary on a GPU (the CPU test
+    test_reference_graph_file_builds_over_this_packages_common shows the reference's own graph file building over
+    this package's models.common - the reference tree itself is not on the GPU box).  Here the HIP-backed modules are
+    driven the way that file drives them: a plain graph walk (restating models/yolo_test.py:235-272), torch's own
+    nn.Upsample between them and a torch Detect (the oracle's restatement of models/yolo_test.py:41-59) on their
+    outputs; the modules compute in the precision of their parameters - fp32, and fp16 after .half()."""
+    import torch.nn as nn
+    from msod_amd.models.common import Focus, Upsample
+    from msod_amd.utils.seeded import seeded_inputs
+    from oracle import cft_oracle as O
+    cfg, model, sd = _seeded("yolov5s_fusion_transformerx3_vedai", 61)
+    rgb, ir = seeded_inputs(2, 96, 160, 61)
+    want_pred, want_raw = O.OracleModel(cfg)(sd, rgb, ir)
+    layers = []
+    for m in model.model:
+        if isinstance(m, Upsample):                      # what the reference's parse_model builds: torch's Upsample
+            t = nn.Upsample(None, 2, "nearest")
+            t.i, t.f = m.i, m.f
+            m = t
+        layers.append(m)
+    for m in model.modules():
+        if isinstance(m, Focus):
+            m.compute_dtype = None                       # precision of the parameters, as under the reference's Model
+    body = nn.Sequential(*layers[:-1]).to(dev)
+    det = layers[-1]
+    ag = O.sorted_anchors(cfg["anchors"])[1]
+
+    def walk(x, x2):
+        y = []
+        for m in body:
+            if m.f == -4:
+                x = m(x2)
+            else:
+                if m.f != -1:
+                    x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+                x = m(x)
+            y.append(x if m.i in model.save else None)
+        feats = [y[j] for j in det.f]
+        torch.cuda.synchronize()
+        return O.detect(sd, f"model.{det.i}.", [f.float().cpu().contiguous() for f in feats], cfg["nc"], ag)
+
+    with torch.no_grad():
+        pred, raw = walk(rgb.to(dev), ir.to(dev))
+        _check_fp32(pred, raw, want_pred, want_raw)
+        body.half()
+        pred, raw = walk(rgb.to(dev).half(), ir.to(dev).half())
+        _check_f16(pred, raw, want_pred, want_raw)

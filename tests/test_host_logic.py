@@ -123,9 +123,9 @@ def test_bad_arguments_return_error_codes_without_gpu():
     assert st == -1 and b"[n][192]" in lib.cft_last_error()
     st = lib.cft_focus_conv(17, 1, 3 * 64 * 64, 64 * 64, 64, 1.0 / 255, 16, 192, None, 16, 64, 0, 1, 64, 64, 64, 1, 0, None)
     assert st == -1 and b"pixel-pair" in lib.cft_last_error()
-    # fused Bottleneck: 64 channels only, and never in place (it reads a halo of x)
-    st = lib.cft_bottleneck(4096, 128, 0, 16, 128, None, 16, 1152, None, 1 << 20, 128, 0, 1, 8, 8, 128, 1, 0, None)
-    assert st == -1 and b"64 channels" in lib.cft_last_error()
+    # fused Bottleneck: 64 / 128 channels only, and never in place (it reads a halo of x)
+    st = lib.cft_bottleneck(4096, 256, 0, 16, 256, None, 16, 2304, None, 1 << 20, 256, 0, 1, 8, 8, 256, 1, 0, None)
+    assert st == -1 and b"64 and 128 channels" in lib.cft_last_error()
     st = lib.cft_bottleneck(4096, 64, 0, 16, 64, None, 16, 576, None, 4096, 64, 0, 1, 8, 8, 64, 1, 0, None)
     assert st == -1 and b"overlaps the input" in lib.cft_last_error()
     st = lib.cft_bottleneck(4096, 128, 0, 16, 64, None, 16, 576, None, 4096 + 64, 128, 0, 1, 8, 8, 64, 1, 0, None)
@@ -210,3 +210,49 @@ def test_concat_plan_routes_producers_into_concat_buffers():
         assert off == (0 if srcs.index(prod) == 0 else total - c) and 0 < c < total
     ups = [s for cidx in concats for s in (cidx + j if j < 0 else j for j in m.model[cidx].f) if type(m.model[s]).__name__ == "Upsample"]
     assert ups and not any(u in plan for u in ups)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_reference_graph_file_builds_over_this_packages_common():
+    """Strict form of the boundary ("models/yolo.py builds unchanged"): the reference's OWN
+    models/yolo_test.py (Model, parse_model with its eval() name lookup and `m is X` identity tests, forward_once,
+    Detect) imported unchanged, with only `models.common` resolved to this package, builds a reference yaml file;
+    its state-dict keys equal those of the reference-on-reference build; and a CPU forward reaches this package's
+    kernels' guard ("no CPU fallback") - i.e. the reference executor is driving the HIP-backed modules.  Run in a
+    subprocess: it puts the reference tree on sys.path."""
+    import subprocess
+    import sys
+    script = f"""
+import sys, types, logging, torch
+for n in ("cv2", "torchvision", "seaborn"):
+    sys.modules.setdefault(n, types.ModuleType(n))
+sys.modules["cv2"].setNumThreads = lambda n: None
+sys.path.insert(0, {REF!r}); sys.path.insert(0, {ROOT!r}); logging.disable(logging.CRITICAL)
+import msod_amd
+from msod_amd import compat
+compat.install_common_alias()
+from models.yolo_test import Model, Detect                      # the REFERENCE's graph file
+import models.yolo_test as ref_graph
+assert ref_graph.__file__.startswith({REF!r})
+m = Model({REF!r} + "/models/transformer/yolov5s_fusion_transformerx3_vedai.yaml")
+kinds = [type(l).__module__.split(".")[0] for l in m.model]
+assert type(m.model[0]).__name__ == "Focus" and type(m.model[0]).__module__.startswith("msod_amd"), kinds
+assert type(m.model[-1]) is Detect and Detect.__module__ == "models.yolo_test"
+assert sum(type(l).__name__ == "GPT" and type(l).__module__.startswith("msod_amd") for l in m.model) == 3
+assert any(type(l) is torch.nn.Upsample for l in m.model)          # the reference's plain torch Upsample stays
+from msod_amd.models.yolo_test import Model as Ours
+from msod_amd.models.configs import named_config
+ours = Ours(named_config("yolov5s_fusion_transformerx3_vedai"))
+assert list(m.state_dict().keys()) == list(ours.state_dict().keys())
+assert all(a.shape == b.shape for a, b in zip(m.state_dict().values(), ours.state_dict().values()))
+try:
+    m.eval()(torch.zeros(1, 3, 64, 64), torch.zeros(1, 3, 64, 64))
+    raise SystemExit("CPU forward did not raise")
+except RuntimeError as e:
+    assert "no CPU fallback" in str(e), e
+m.fuse()                                                         # the reference's fuse(): type(m) is Conv, .bn, .fuseforward
+assert not hasattr(m.model[1], "bn") and m.model[1].conv.bias is not None
+print("STRICT-FORM-OK")
+"""
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True)
+    assert r.returncode == 0 and "STRICT-FORM-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -119,3 +119,50 @@ def test_hip_nms_max_nms_truncation_and_labels(dev):
     got = non_max_suppression(p1.to(dev), 0.25, 0.45, labels=lab)[0].cpu()
     assert got.shape == want.shape and torch.allclose(got[2:], want[2:], rtol=0, atol=1e-4)
     assert sorted(got[:2, 5].tolist()) == [0.0, 2.0] and (got[:2, 4] == 1.0).all()      # the two labels tie at conf 1.0
+
+
+def _clustered_pred(n_clusters, per_cluster, nc=2, tie_scores=False):
+    """Clusters of near-identical boxes (one survivor each); cluster c's scores sit in a band below cluster c-1's, so
+    the survivors are spread over the whole score range: the kernel must walk several LDS chunks to find 300 of them."""
+    g = torch.Generator().manual_seed(7)
+    rows = n_clusters * per_cluster
+    p = torch.zeros(1, rows, nc + 5)
+    c = torch.arange(n_clusters).repeat_interleave(per_cluster)
+    p[0, :, 0] = 40.0 + (c % 40) * 60.0 + torch.rand(rows, generator=g) * 2
+    p[0, :, 1] = 40.0 + (c // 40) * 60.0 + torch.rand(rows, generator=g) * 2
+    p[0, :, 2:4] = 30.0
+    p[0, :, 4] = 0.9 if tie_scores else (0.99 - c.float() * 0.002 - torch.rand(rows, generator=g) * 0.0015)
+    p[0, :, 5] = 1.0
+    p[0, :, 6] = 0.1
+    perm = torch.randperm(rows, generator=g)
+    return p[:, perm].contiguous()
+
+
+@pytest.mark.gpu
+def test_hip_nms_walks_several_lds_chunks(dev):
+    """> 2048 candidates and fewer than max_det survivors in the first chunk: later chunks are thinned by the boxes
+    kept so far and continue the greedy order exactly."""
+    from msod_amd.utils.general import batched_nms
+    p = _clustered_pred(320, 20)                         # 6400 candidates, 320 clusters -> 300 kept, spread over all chunks
+    want = nms_oracle.non_max_suppression(p, 0.25, 0.45)[0]
+    dets, counts = batched_nms(p.to(dev), 0.25, 0.45)
+    got = dets[0, :int(counts[0])].cpu()
+    assert want.shape[0] == 300 and got.shape == want.shape and torch.equal(got, want)
+    p2 = _clustered_pred(120, 40)                        # 4800 candidates, only 120 survivors: every chunk is visited
+    want = nms_oracle.non_max_suppression(p2, 0.25, 0.45)[0]
+    dets, counts = batched_nms(p2.to(dev), 0.25, 0.45)
+    got = dets[0, :int(counts[0])].cpu()
+    assert want.shape[0] == 120 and got.shape == want.shape and torch.equal(got, want)
+
+
+@pytest.mark.gpu
+def test_hip_nms_score_ties_overflowing_a_chunk(dev):
+    """5000 candidates with IDENTICAL confidence: the chunk threshold ties with all of them, the LDS arrays cannot hold
+    the chunk and the kernel falls back to rounds over global memory; ties resolve by row order like the oracle's
+    stable sort."""
+    from msod_amd.utils.general import batched_nms
+    p = _clustered_pred(250, 20, tie_scores=True)
+    want = nms_oracle.non_max_suppression(p, 0.25, 0.45)[0]
+    dets, counts = batched_nms(p.to(dev), 0.25, 0.45)
+    got = dets[0, :int(counts[0])].cpu()
+    assert want.shape[0] == 250 and got.shape == want.shape and torch.equal(got, want)

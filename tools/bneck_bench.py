@@ -1,5 +1,8 @@
-"""Time cft_bottleneck (64-channel stage, 160x160, batch 64) against the two cft_conv2d launches it replaces, and
-its ablation probes (variants 901 = no phase 1, 902 = no phase-2 MFMAs, 904 = no epilogue, 907 = none of them)."""
+"""Time cft_bottleneck against the two cft_conv2d launches it replaces, and its ablation probes.
+    python tools/bneck_bench.py [C] [variants]      C = 64 (160x160 stage) or 128 (80x80 stage), batch 64
+64 channels: 901 = no phase 1, 902 = no phase-2 MFMAs, 904 = no epilogue, 907 = none of them.
+128 channels: 901 = no t-patch MFMAs, 902 = no 3x3 MFMAs, 904 = no epilogue, 908 = no weight DMA."""
+import json
 import os
 import sys
 
@@ -27,23 +30,30 @@ def main():
     dev = torch.device("cuda:0")
     lib = _lib.load()
     g = torch.Generator().manual_seed(0)
-    B, H, W = 64, 160, 160
-    cat = ops.new_nhwc(B, H, W, 128, torch.bfloat16, dev)
+    C = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    B, H, W = (64, 160, 160) if C == 64 else (64, 80, 80)
+    cat = ops.new_nhwc(B, H, W, 2 * C, torch.bfloat16, dev)
     cat.copy_(torch.randn(cat.shape, device=dev))
-    x = cat[:, :64]
-    pk1 = ops.pack_conv(torch.randn(64, 64, 1, 1, generator=g) / 8, torch.randn(64, generator=g) * 0.1, torch.bfloat16, device=dev)
-    pk2 = ops.pack_conv(torch.randn(64, 64, 3, 3, generator=g) / 24, torch.randn(64, generator=g) * 0.1, torch.bfloat16, device=dev)
-    out = ops.new_nhwc(B, H, W, 64, torch.bfloat16, dev)
-    t = ops.new_nhwc(B, H, W, 64, torch.bfloat16, dev)
-    only = sys.argv[1:] and [int(v) for v in sys.argv[1].split(",")]
+    x = cat[:, :C]
+    pk1 = ops.pack_conv(torch.randn(C, C, 1, 1, generator=g) / C ** 0.5, torch.randn(C, generator=g) * 0.1, torch.bfloat16, device=dev)
+    pk2 = ops.pack_conv(torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5), torch.randn(C, generator=g) * 0.1, torch.bfloat16, device=dev)
+    out = ops.new_nhwc(B, H, W, C, torch.bfloat16, dev)
+    t = ops.new_nhwc(B, H, W, C, torch.bfloat16, dev)
+    only = len(sys.argv) > 2 and [int(v) for v in sys.argv[2].split(",")]
+    flops = 2.0 * B * H * W * C * C * 10
+    res = {"C": C, "gflop": flops / 1e9}
     if not only:
         us = timeit(lambda: ops.conv2d(ops.conv2d(x, pk1, 1, out=t), pk2, 1, residual=x, out=out))
-        print(f"two launches: {us:.1f} us")
-    for v in (only or (0, 901, 902, 904, 907)):
+        res["two_launches_us"] = round(us, 1)
+        print(f"two launches: {us:.1f} us  ({flops / us / 1e6:.0f} TFLOP/s)")
+    for v in (only or ((0, 901, 902, 904, 907) if C == 64 else (0, 901, 902, 904, 908))):
         lib.cft_set_conv_variant(v)
         us = timeit(lambda: ops.bottleneck(x, pk1, pk2, True, out=out))
-        print(f"fused variant {v}: {us:.1f} us")
+        res[f"fused_v{v}_us"] = round(us, 1)
+        print(f"fused variant {v}: {us:.1f} us  ({flops / us / 1e6:.0f} TFLOP/s)")
     lib.cft_set_conv_variant(0)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", f"bneck_bench_c{C}.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
