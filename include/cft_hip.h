@@ -156,9 +156,11 @@ int cft_layernorm(const float* x, const float* gamma, const float* beta, void* y
  * qkv : dtype [B*128, 3*heads*dkp]: row = token, columns [which(q,k,v)][head][dkp]; dkp is the
  * head width padded with zeros to a multiple of 32 (bf16) / 16 (f32); dk the true head width.
  * out : dtype [B*128, heads*dkp].
+ * attn_pdrop / seed: training-mode dropout of the attention probabilities (models/common.py:507 `attn_drop`), applied
+ * inside the kernel with the counter-based mask of cft_dropout; 0 = inference.
  */
 int cft_attention(const void* qkv, void* out, int B, int heads, int dk, int dkp,
-                  int dtype, void* stream);
+                  int dtype, float attn_pdrop, unsigned long long seed, void* stream);
 
 /*
  * CFT de-tokeniser fused with the residual add (models/common.py:626-637 + Add2 :238-243):
@@ -180,6 +182,26 @@ int cft_gpt_upsample_add(const float* tokens, int s, const void* base, int ldb, 
 int cft_detect_decode(const float* logits, int ldl, float* raw, float* pred, const float* anchors,
                       int B, int ny, int nx, int na, int no, float stride,
                       long row0, long total_rows, void* stream);
+
+/*
+ * Training-mode forward (forward only, no autograd).
+ *
+ * cft_batchnorm_train: BatchNorm2d with BATCH statistics on the fp32 conv output x [M, ldx] (channels xoff..xoff+C), as
+ * `act(bn(conv(x)))` does when `bn.training` (models/common.py:45-47): biased variance for the normalisation, running
+ * statistics updated in place with `momentum` and the unbiased variance (torch semantics; NULL = do not track), then
+ * SiLU / none, optional residual add (Bottleneck shortcut, :108-109) and the store into an NHWC channel slice in
+ * `out_dtype`.  workspace: cft_batchnorm_train_workspace(M, C) bytes of device memory.
+ *
+ * cft_dropout: in-place nn.Dropout(p) in training mode on a contiguous tensor of n elements (GPT.drop :611, resid_drop
+ * :511, the MLP's Dropout :537): element i is kept iff hash(seed, i) >= p * 2^32 and scaled by 1/(1-p).
+ */
+long cft_batchnorm_train_workspace(long M, int C);
+int cft_batchnorm_train(const float* x, int ldx, int xoff, long M, int C,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        float momentum, float eps, const void* res, int ldr, int roff, int res_dtype,
+                        void* y, int ldy, int yoff, int act, int out_dtype,
+                        void* workspace, long workspace_bytes, void* stream);
+int cft_dropout(void* x, long n, float p, unsigned long long seed, int dtype, void* stream);
 
 /*
  * Batched NMS on the decoded predictions (utils/general.py:455-543 `non_max_suppression`, incl. the

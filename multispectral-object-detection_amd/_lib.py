@@ -15,7 +15,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcft_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("runtime.hip", "conv_gemm.hip", "focus_conv.hip", "bottleneck.hip", "pointwise.hip", "attention.hip", "nms.hip")
+SOURCES = ("runtime.hip", "conv_gemm.hip", "focus_conv.hip", "bottleneck.hip", "pointwise.hip", "attention.hip", "nms.hip", "train.hip")
 
 CFT_BF16, CFT_F32, CFT_F16 = 0, 1, 2
 ABI_VERSION = 2
@@ -40,7 +40,10 @@ SIGNATURES = {
     "cft_add": [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _l, _i, _i, _vp],
     "cft_gpt_tokenize": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cft_layernorm": [_vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp],
-    "cft_attention": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "cft_attention": [_vp, _vp, _i, _i, _i, _i, _i, _f, _c.c_ulonglong, _vp],
+    "cft_batchnorm_train": [_vp, _i, _i, _l, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _l, _vp],
+    "cft_dropout": [_vp, _l, _f, _c.c_ulonglong, _i, _vp],
+    "cft_batchnorm_train_workspace": [_l, _i],      # returns long (bytes)
     "cft_gpt_upsample_add": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_nms": [_vp, _i, _i, _i, _f, _f, _i, _i, _vp, _i, _i, _vp, _l, _vp, _vp, _vp],
     "cft_detect_decode": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _l, _vp],
@@ -81,6 +84,7 @@ def load():
         fn.restype = ctypes.c_int
     lib.cft_last_error.argtypes = []
     lib.cft_last_error.restype = ctypes.c_char_p
+    lib.cft_batchnorm_train_workspace.restype = ctypes.c_long
     _lib = lib
     return lib
 

@@ -15,7 +15,8 @@
 
 template <typename T>
 __global__ void __launch_bounds__(256) attention_kernel(const unsigned char* __restrict__ qkv, unsigned char* __restrict__ out,
-                                                        int heads, int dkp, float scale) {
+                                                        int heads, int dkp, float scale, uint32_t drop_thresh, float inv_keep,
+                                                        unsigned long long seed) {
   constexpr int GE = Elem<T>::GE;
   constexpr int ES = (int)sizeof(T);
   constexpr int T_TOK = 128;
@@ -108,6 +109,15 @@ __global__ void __launch_bounds__(256) attention_kernel(const unsigned char* __r
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     inv_sum[i] = 1.0f / sum;
+    if (drop_thresh != 0u) {   // training: attn_drop on the normalised probabilities (reference models/common.py:507); the
+                               // normaliser is linear, so masking + 1/(1-p) scaling the unnormalised exponentials is the same
+      const unsigned long long qrow = ((unsigned long long)blockIdx.x * T_TOK + (wave * 32 + i * 16 + lrow)) * T_TOK;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          s[i][j][e] = cft_hash32(seed, qrow + (unsigned)(j * 16 + lgrp * 4 + e)) >= drop_thresh ? s[i][j][e] * inv_keep : 0.0f;
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       if constexpr (ES == 2) {
@@ -176,8 +186,9 @@ __global__ void __launch_bounds__(256) attention_kernel(const unsigned char* __r
 }
 
 extern "C" int cft_attention(const void* qkv, void* out, int B, int heads, int dk, int dkp,
-                             int dtype, void* stream) {
+                             int dtype, float attn_pdrop, unsigned long long seed, void* stream) {
   CFT_REQUIRE(qkv && out, "cft_attention: null pointer");
+  CFT_REQUIRE(attn_pdrop >= 0.0f && attn_pdrop < 1.0f, "cft_attention: attn_pdrop must be in [0, 1) (0 = inference)");
   CFT_REQUIRE(cft_is_dtype(dtype), "cft_attention: bad dtype");
   const int es = cft_elem_size(dtype);
   const int kstep = es == 2 ? 32 : 16;
@@ -188,7 +199,8 @@ extern "C" int cft_attention(const void* qkv, void* out, int B, int heads, int d
   const float scale = 1.0f / sqrtf((float)dk);
   CFT_DISPATCH_DTYPE(dtype, T, {
     cft_allow_lds<&attention_kernel<T>>(160 * 1024);
-    hipLaunchKernelGGL(attention_kernel<T>, dim3(B * heads), dim3(256), smem, as_stream(stream), (const unsigned char*)qkv, (unsigned char*)out, heads, dkp, scale);
+    hipLaunchKernelGGL(attention_kernel<T>, dim3(B * heads), dim3(256), smem, as_stream(stream), (const unsigned char*)qkv, (unsigned char*)out, heads, dkp, scale,
+                       (uint32_t)((double)attn_pdrop * 4294967296.0), 1.0f / (1.0f - attn_pdrop), seed);
   });
   return cft_check_launch("attention_kernel");
 }

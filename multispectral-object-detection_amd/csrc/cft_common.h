@@ -123,6 +123,15 @@ __device__ __forceinline__ float apply_act(float v) {
   return v;
 }
 
+// Counter-based uniform 32-bit hash of (seed, element index) for dropout masks (splitmix64 finaliser).
+__device__ __forceinline__ uint32_t cft_hash32(unsigned long long seed, unsigned long long i) {
+  unsigned long long z = seed + (i + 1ull) * 0x9E3779B97F4A7C15ull;     // splitmix64
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+
 // ---- host side -----------------------------------------------------------------------------
 void cft_set_error(const char* msg);
 int cft_check_launch(const char* what);

@@ -21,8 +21,10 @@ every class, however, launches hand-written gfx950 kernels through ``libcft_hip.
               out-proj(+residual) -> LayerNorm -> fc1(+GELU) -> fc2(+residual); the bilinear
               upsampling is deferred and fused with the Add2 that consumes it.
 
-Inference only (BatchNorm uses running statistics, dropout is the identity) - training forward
-is out of scope and raises.
+``model.eval()`` (the default, the benchmarked path): BatchNorm folded into the conv weights, dropout the identity.
+``model.train()``: the training-mode FORWARD of the reference: BatchNorm with batch
+statistics and running-stat updates (``cft_batchnorm_train`` after an un-folded conv), dropout in GPT / SelfAttention /
+MLP (``cft_dropout``, counter-based masks), ``Detect`` returning the raw list.  No autograd graph is built.
 """
 import math
 
@@ -99,6 +101,7 @@ def invalidate_packed(root):
     with."""
     for m in root.modules():
         m.__dict__.pop("_cft_cache", None)
+        m.__dict__.pop("_cft_cache_train", None)
         if "_graphs" in m.__dict__:
             m.__dict__["_graphs"].clear()
         m.__dict__.pop("_wlist", None)
@@ -107,17 +110,20 @@ def invalidate_packed(root):
 class _Packed(nn.Module):
     """Mixin: lazily packed kernel-side weights, rebuilt when dtype/device/parameters change."""
 
-    def _packed(self, dtype, device):
-        if self.training:
-            raise RuntimeError(f"{type(self).__name__}: only the inference forward is implemented "
-                               "(call model.eval()); training is out of scope")
-        key = _cache_key(self, dtype, device)
-        cache = self.__dict__.get("_cft_cache")
+    def _packed(self, dtype, device, train=False):
+        """Kernel-side weights for the inference form (BatchNorm folded) or, ``train=True``, the training form
+        (``_pack_train``: un-folded conv weights)."""
+        key = (train,) + _cache_key(self, dtype, device)
+        slot = "_cft_cache_train" if train else "_cft_cache"
+        cache = self.__dict__.get(slot)
         if cache is None or cache[0] != key:
             with torch.no_grad():
-                cache = (key, self._pack(dtype, device))
-            self.__dict__["_cft_cache"] = cache
+                cache = (key, self._pack_train(dtype, device) if train else self._pack(dtype, device))
+            self.__dict__[slot] = cache
         return cache[1]
+
+    def _pack_train(self, dtype, device):
+        raise NotImplementedError(f"{type(self).__name__} has no training-mode form")
 
     def _pack(self, dtype, device):
         raise NotImplementedError
@@ -164,8 +170,18 @@ class Conv(_Packed):
         w, b = _folded(self)
         return ops.pack_conv(w, b, dtype, s=self.conv.stride[0], cin_pad=cin_pad, device=device)
 
+    cin_pad = None      # Focus sets 16 on its inner Conv (space-to-depth output is padded to 16 channels)
+
+    def _pack_train(self, dtype, device):
+        return ops.pack_conv(self.conv.weight.float(), None, dtype, s=self.conv.stride[0], cin_pad=self.cin_pad, device=device)
+
     def forward(self, x, residual=None, out=None):
         x = resolve(x)
+        if self.training and hasattr(self, "bn") and self.bn.training:
+            # act(bn(conv(x))) with batch statistics (reference :45-47): fp32 conv output, then cft_batchnorm_train
+            pk = self._packed(x.dtype, x.device, train=True)
+            y32 = ops.conv2d(x, pk, ACT_NONE, out_dtype=torch.float32)
+            return ops.batchnorm_train(y32, pk.n_valid, self.bn, _act_code(self.act), residual=residual, out=out, out_dtype=x.dtype)
         return ops.conv2d(x, self._packed(x.dtype, x.device), _act_code(self.act), residual=residual, out=out)
 
     fuseforward = forward  # the kernel always runs the folded form (reference :49-50)
@@ -215,7 +231,13 @@ class C3(_Packed):
         c_ = self.cv1.conv.out_channels
         if _act_code(self.cv1.act) != _act_code(self.cv2.act):
             raise NotImplementedError("C3.cv1 and C3.cv2 must share an activation")
-        cat = ops.conv2d(x, self._packed(x.dtype, x.device), _act_code(self.cv1.act))     # [B, 2c_, H, W]
+        if self.training:      # batch statistics are per BatchNorm: cv1 and cv2 run separately into the concat buffer
+            B, _, H, W = x.shape
+            cat = ops.new_nhwc(B, H, W, 2 * c_, x.dtype, x.device)
+            self.cv1(x, out=cat[:, :c_])
+            self.cv2(x, out=cat[:, c_:])
+        else:
+            cat = ops.conv2d(x, self._packed(x.dtype, x.device), _act_code(self.cv1.act))     # [B, 2c_, H, W]
         head = cat[:, :c_]
         y = head
         n = len(self.m)
@@ -259,6 +281,7 @@ class Focus(_Packed):
     def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
         super().__init__()
         self.conv = Conv(c1 * 4, c2, k, s, p, g, act)
+        self.conv.cin_pad = 16
 
     def _pack(self, dtype, device):
         if self.conv.conv.in_channels != 12:
@@ -268,6 +291,9 @@ class Focus(_Packed):
     def forward(self, x):
         x = resolve(x)
         dtype = self.compute_dtype or self.conv.conv.weight.dtype
+        if self.training:      # space-to-depth, then the Conv's training form (batch statistics)
+            self.conv.cin_pad = 16
+            return self.conv(ops.focus_s2d(x, dtype))
         return ops.focus_conv(x, self._packed(dtype, x.device), _act_code(self.conv.act), dtype)
 
 
@@ -396,7 +422,11 @@ class SelfAttention(_Packed):
         qkv_w, out_w, dkp = self._packed(x.dtype, x.device)
         B = x.shape[0] // 128
         qkv = ops.linear(x, qkv_w)
-        att = ops.attention(qkv, B, self.h, self.d_k, dkp)
+        att = ops.attention(qkv, B, self.h, self.d_k, dkp, pdrop=self.attn_drop.p if self.training else 0.0)
+        if self.training and self.resid_drop.p > 0 and residual is not None:
+            proj = ops.linear(att, out_w, out_dtype=torch.float32)          # resid_drop(out_proj(.)) then the residual add
+            ops.dropout_(proj, self.resid_drop.p)
+            return ops.add_rows_(residual, proj)
         return ops.linear(att, out_w, residual=residual, out=residual,
                           out_dtype=torch.float32 if residual is not None else None)
 
@@ -429,6 +459,11 @@ class myTransformerBlock(_Packed):
         self.sa(y, residual=x)                                   # x += out_proj(attention(LN(x)))
         y = ops.layernorm(x, ln[2], ln[3], compute_dtype, self.ln_output.eps)
         hid = ops.linear(y, fc1, act=ACT_GELU)
+        pd = self.mlp[3].p if (self.training and len(self.mlp) > 3) else 0.0
+        if pd > 0:
+            z = ops.linear(hid, fc2, out_dtype=torch.float32)
+            ops.dropout_(z, pd)
+            return ops.add_rows_(x, z)
         ops.linear(hid, fc2, residual=x, out=x, out_dtype=torch.float32)  # x += fc2(gelu(fc1(LN(x))))
         return x
 
@@ -466,8 +501,6 @@ class GPT(_Packed):
         return _f32(self.pos_emb, device), _f32(self.ln_f.weight, device), _f32(self.ln_f.bias, device)
 
     def forward(self, x):
-        if self.training:
-            raise RuntimeError("GPT: only the inference forward is implemented (call model.eval())")
         if self.vert_anchors != 8 or self.horz_anchors != 8:
             raise NotImplementedError("the CFT kernels are specialised for the 8x8 anchor grid (128 tokens)")
         rgb, ir = resolve(x[0]), resolve(x[1])
@@ -478,6 +511,8 @@ class GPT(_Packed):
         dtype = rgb.dtype
         pos_emb, lnf_w, lnf_b = self._packed(dtype, rgb.device)
         tok = ops.gpt_tokenize(rgb, ir, pos_emb)                 # fp32 [B,128,C], pos_emb added
+        if self.training:
+            ops.dropout_(tok, self.drop.p)                       # self.drop(pos_emb + token_embeddings), reference :611
         t2 = tok.view(B * 128, C)
         for blk in self.trans_blocks:
             blk(t2, dtype)

@@ -65,8 +65,8 @@ class Detect(_Packed):
         return [ops.pack_conv(m.weight, m.bias, dtype, device=device) for m in self.m], anchors_px
 
     def forward(self, x):
-        if self.training or self.export:
-            raise RuntimeError("Detect: only the inference branch (models/yolo_test.py:50-59) is implemented")
+        if self.export:
+            raise RuntimeError("Detect: the ONNX-export branch is outside the hot path")
         x = [resolve(t) for t in x]
         packed, anchors_px = self._packed(x[0].dtype, x[0].device)
         B = x[0].shape[0]
@@ -81,7 +81,7 @@ class Detect(_Packed):
             ops.detect_decode(logits, raw, pred, anchors_px[i], self.na, self.no, float(self.stride[i]), row0)
             raws.append(raw)
             row0 += rows[i]
-        return pred, raws
+        return raws if self.training else (pred, raws)      # training: only the raw list (reference :59)
 
 
 def check_anchor_order(m):
@@ -238,7 +238,7 @@ class Model(nn.Module):
             raise ValueError(f"image height and width must be multiples of the largest stride ({smax}); got "
                              f"{x.shape[2]}x{x.shape[3]} (the reference letterboxes to such sizes, utils/datasets.py:1698-1728)")
         key = (tuple(x.shape), self.compute_dtype, x.dtype)
-        g = self._graphs.get(key)
+        g = None if self.training else self._graphs.get(key)
         if g is not None:
             if g.weights_key == self.weights_key():
                 return g.replay(x, x2)

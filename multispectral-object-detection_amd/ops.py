@@ -404,12 +404,14 @@ def layernorm(x, gamma, beta, out_dtype, eps=1e-5):
     return out
 
 
-def attention(qkv, B, heads, dk, dkp):
+def attention(qkv, B, heads, dk, dkp, pdrop=0.0):
+    """``pdrop`` > 0: training-mode dropout of the attention probabilities inside the kernel."""
     _require_cuda(qkv, "attention")
     out = torch.empty((B * 128, heads * dkp), dtype=qkv.dtype, device=qkv.device)
     lib = _lib.load()
+    seed = next_dropout_seed() if pdrop > 0 else 0
     st = _timed("cft_attention", 4.0 * 128 * 128 * dk * heads * B, 4.0 * B * 128 * heads * dkp * qkv.element_size(),
-                lambda: lib.cft_attention(qkv.data_ptr(), out.data_ptr(), B, heads, dk, dkp, _dt(qkv.dtype), _stream()))
+                lambda: lib.cft_attention(qkv.data_ptr(), out.data_ptr(), B, heads, dk, dkp, _dt(qkv.dtype), float(pdrop), seed, _stream()))
     _lib.check(st, "cft_attention")
     return out
 
@@ -439,3 +441,72 @@ def detect_decode(logits, raw, pred, anchors_px, na, no, stride, row0):
                                        B, ny, nx, na, no, float(stride), row0, pred.shape[1], _stream())
     _lib.check(st, "cft_detect_decode")
 
+
+
+# ------------------------------------------------------------------------------ training-mode forward
+_dropout_state = {"seed": 0x5EED, "calls": 0}
+
+
+def manual_dropout_seed(seed):
+    """Seed of the counter-based dropout masks (every dropout call of a forward draws seed + call index)."""
+    _dropout_state["seed"], _dropout_state["calls"] = int(seed), 0
+
+
+def next_dropout_seed():
+    _dropout_state["calls"] += 1
+    return (_dropout_state["seed"] * 0x9E3779B1 + _dropout_state["calls"]) & 0xFFFFFFFFFFFFFFFF
+
+
+def dropout_(x, p):
+    """In-place nn.Dropout(p) in training mode on a contiguous tensor (cft_dropout)."""
+    _require_cuda(x, "dropout_")
+    if p <= 0.0:
+        return x
+    if not x.is_contiguous():
+        raise ValueError("dropout_: tensor must be contiguous")
+    st = _lib.load().cft_dropout(x.data_ptr(), x.numel(), float(p), next_dropout_seed(), _dt(x.dtype), _stream())
+    _lib.check(st, "cft_dropout")
+    return x
+
+
+def add_rows_(x, y):
+    """x += y for two [rows, C] tensors of one dtype (the CFT residual stream in training mode)."""
+    rows, C = x.shape
+    st = _lib.load().cft_add(x.data_ptr(), x.stride(0), 0, y.data_ptr(), y.stride(0), 0, x.data_ptr(), x.stride(0), 0, rows, C, _dt(x.dtype), _stream())
+    _lib.check(st, "cft_add(rows)")
+    return x
+
+
+def batchnorm_train(y32, C, bn, act, residual=None, out=None, out_dtype=None):
+    """act(BatchNorm2d(y32)) with BATCH statistics (+ residual) and the running-statistics update of ``bn``
+    (an nn.BatchNorm2d in training mode): y32 is the fp32 conv output [B, pad8(C), H, W] (NHWC)."""
+    _require_cuda(y32, "batchnorm_train")
+    B, Cp, H, W = y32.shape
+    ldx = _view_ld(y32, "batchnorm_train input")
+    out_dtype = out_dtype or torch.float32
+    if out is None:
+        out = new_nhwc(B, H, W, Cp, out_dtype, y32.device)[:, :C] if Cp != C else new_nhwc(B, H, W, C, out_dtype, y32.device)
+    if tuple(out.shape) != (B, C, H, W):
+        raise ValueError(f"batchnorm_train: out has shape {tuple(out.shape)}, expected {(B, C, H, W)}")
+    ldy = _view_ld(out, "batchnorm_train out")
+    for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != y32.device:
+            raise TypeError("batchnorm_train: BatchNorm parameters / running statistics must be contiguous fp32 tensors on the GPU")
+    rp, ldr, rdt = None, 0, CFT_F32
+    if residual is not None:
+        if tuple(residual.shape) != (B, C, H, W):
+            raise ValueError("batchnorm_train: residual shape mismatch")
+        ldr, rp, rdt = _view_ld(residual, "batchnorm_train residual"), residual.data_ptr(), _dt(residual.dtype)
+    lib = _lib.load()
+    M = B * H * W
+    ws = torch.empty((lib.cft_batchnorm_train_workspace(M, C),), dtype=torch.uint8, device=y32.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    mom = 0.0 if bn.momentum is None else float(bn.momentum)
+    st = lib.cft_batchnorm_train(y32.data_ptr(), ldx, 0, M, C, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                 bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                                 mom, float(bn.eps), rp, ldr, 0, rdt, out.data_ptr(), ldy, 0, act, _dt(out.dtype),
+                                 ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(st, "cft_batchnorm_train")
+    if track and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return out

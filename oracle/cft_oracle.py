@@ -28,8 +28,15 @@ import torch
 import torch.nn.functional as F
 
 BN_EPS = 1e-3  # utils/torch_utils.py:150
+BN_MOMENTUM = 0.03  # utils/torch_utils.py:151
 LN_EPS = 1e-5  # nn.LayerNorm default, models/common.py:529-530,572
 STRIDES = (8.0, 16.0, 32.0)  # models/yolo_test.py:201
+
+# Training-mode forward (model.train(); models/common.py:45-47 with bn.training, models/yolo_test.py:50,59): while an
+# OracleModel call with train=True is running this dict collects the updated BatchNorm running statistics
+# {state-dict key: tensor}; BatchNorm then normalises with BATCH statistics.  Dropout (models/common.py:507,511,537,611)
+# draws from torch's RNG and is only restated for p = 0 (identity) - the tests set every Dropout.p to 0 for parity.
+_TRAIN = None
 
 
 def make_divisible(x, divisor):  # utils/general.py:210-212
@@ -103,8 +110,13 @@ def conv_bn_silu(sd, p, x, k, s, act=True):
     w = sd[p + "conv.weight"]
     if p + "bn.weight" in sd:
         y = F.conv2d(x, w, None, s, k // 2)
-        y = F.batch_norm(y, sd[p + "bn.running_mean"], sd[p + "bn.running_var"],
-                         sd[p + "bn.weight"], sd[p + "bn.bias"], False, 0.0, BN_EPS)
+        if _TRAIN is not None:      # bn.training: batch statistics, running statistics updated (momentum 0.03)
+            rm, rv = sd[p + "bn.running_mean"].clone(), sd[p + "bn.running_var"].clone()
+            y = F.batch_norm(y, rm, rv, sd[p + "bn.weight"], sd[p + "bn.bias"], True, BN_MOMENTUM, BN_EPS)
+            _TRAIN[p + "bn.running_mean"], _TRAIN[p + "bn.running_var"] = rm, rv
+        else:
+            y = F.batch_norm(y, sd[p + "bn.running_mean"], sd[p + "bn.running_var"],
+                             sd[p + "bn.weight"], sd[p + "bn.bias"], False, 0.0, BN_EPS)
     else:
         y = F.conv2d(x, w, sd[p + "conv.bias"], s, k // 2)
     return F.silu(y) if act else y
@@ -221,7 +233,17 @@ class OracleModel:
         self.layers, self.save = build_graph(cfg, ch)
 
     @torch.no_grad()
-    def __call__(self, sd, rgb, ir, taps=None, tap_all=False):
+    def __call__(self, sd, rgb, ir, taps=None, tap_all=False, train=False):
+        """train=True: the training-mode forward (BatchNorm batch statistics, Detect returns only the raw list,
+        models/yolo_test.py:59); returns (raw list, {updated running statistics})."""
+        global _TRAIN
+        if train:
+            _TRAIN = {}
+            try:
+                _, raws = self.__call__(sd, rgb, ir, taps, tap_all)
+                return raws, _TRAIN
+            finally:
+                _TRAIN = None
         sd = {k: v.float() if v.is_floating_point() else v for k, v in sd.items()}
         y = []
         x = rgb.float()

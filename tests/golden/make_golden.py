@@ -146,8 +146,40 @@ def make_checkpoint():
     print(f"ref_ckpt_tiny.pt {os.path.getsize(path)/1e3:.0f} kB, pred {tuple(pred.shape)}, raw std {raw[0].std():.3f}")
 
 
+def make_train_golden():
+    """The reference's own TRAINING-mode forward (model.train(): BatchNorm batch statistics + running-stat updates,
+    Detect returning the raw list, models/yolo_test.py:59) with every nn.Dropout probability set to 0 (torch's dropout
+    RNG stream is not reproducible elsewhere); pins oracle/cft_oracle.py's train=True path."""
+    install_reference()
+    sys.path.insert(0, ROOT)
+    import msod_amd  # noqa: F401
+    from msod_amd.models.configs import named_config
+    from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict
+    from models.yolo_test import Model  # the reference
+    cfg_name, b, h, w, seed = "yolov5s_fusion_transformerx3_vedai", 2, 96, 128, 8
+    cfg = named_config(cfg_name)
+    torch.manual_seed(0)
+    model = Model(cfg)
+    model.load_state_dict(seeded_state_dict(model.state_dict(), seed))
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    rgb, ir = seeded_inputs(b, h, w, seed)
+    with torch.no_grad():
+        raws = model(rgb, ir)
+    assert isinstance(raws, list) and len(raws) == 3
+    stats = {k: v.clone() for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+    path = os.path.join(HERE, "s_x3_train_96.pt")
+    torch.save({"case": dict(name="s_x3_train_96", cfg=cfg_name, batch=b, height=h, width=w, seed=seed, train=True),
+                "torch": torch.__version__, "raw": [r.clone() for r in raws], "stats": stats}, path)
+    print(f"s_x3_train_96 raw {[tuple(r.shape) for r in raws]} std {raws[0].std():.3f}, {len(stats)} statistics -> {os.path.getsize(path)/1e3:.0f} kB")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "nms":
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        make_train_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "nms":
         make_nms_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "ckpt":
         make_checkpoint()
@@ -155,3 +187,4 @@ if __name__ == "__main__":
         main()
         make_nms_golden()
         make_checkpoint()
+        make_train_golden()

@@ -103,7 +103,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = _lib.load()
     assert lib.cft_abi_version() == 2
     header = open(os.path.join(ROOT, "include", "cft_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(cft_\w+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^\s*(?:int|long|const char\*)\s+(cft_\w+)\s*\(", header, re.M))
     assert declared == set(_lib.SIGNATURES) | {"cft_last_error"}, declared ^ (set(_lib.SIGNATURES) | {"cft_last_error"})
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:

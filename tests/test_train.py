@@ -1,0 +1,138 @@
+"""Training-mode forward: BatchNorm batch statistics + running-stat updates, Detect's raw list,
+dropout.  CPU: the oracle's train=True path against the reference's own model.train() forward (tests/golden/
+s_x3_train_96.pt, every Dropout.p = 0).  GPU: the HIP training forward against the oracle, and dropout statistics."""
+import os
+
+import pytest
+import torch
+
+import msod_amd  # noqa: F401
+from msod_amd.models.configs import named_config
+from msod_amd.models.yolo_test import Model
+from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict
+from oracle.cft_oracle import OracleModel
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _case():
+    g = torch.load(os.path.join(HERE, "golden", "s_x3_train_96.pt"), weights_only=False)
+    c = g["case"]
+    cfg = named_config(c["cfg"])
+    model = Model(cfg)
+    sd = seeded_state_dict(model.state_dict(), c["seed"])
+    model.load_state_dict(sd)
+    rgb, ir = seeded_inputs(c["batch"], c["height"], c["width"], c["seed"])
+    return g, cfg, model, sd, rgb, ir
+
+
+def test_oracle_train_forward_reproduces_the_reference():
+    g, cfg, model, sd, rgb, ir = _case()
+    raws, stats = OracleModel(cfg)(sd, rgb, ir, train=True)
+    assert len(raws) == 3
+    for a, b in zip(raws, g["raw"]):
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-5
+    ref = {k: v for k, v in g["stats"].items() if not k.endswith("num_batches_tracked")}
+    assert set(stats) == set(ref)
+    for k, v in ref.items():
+        assert torch.allclose(stats[k], v, rtol=1e-5, atol=1e-6), k
+    assert all(int(v) == 1 for k, v in g["stats"].items() if k.endswith("num_batches_tracked"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["f32", "f16"])
+def test_hip_train_forward_matches_oracle(dev, dtype):
+    """model.train() with every Dropout.p = 0: the raw list equals the oracle's / the reference's (fp32: 1e-3 on the
+    logits; fp16: 1e-2 in sigmoid space) and every BatchNorm's running statistics are updated like torch updates them."""
+    g, cfg, model, sd, rgb, ir = _case()
+    model = model.to(dev).set_compute_dtype(dtype).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    with torch.no_grad():
+        raws = model(rgb.to(dev), ir.to(dev))
+    torch.cuda.synchronize()
+    assert isinstance(raws, list) and len(raws) == 3
+    want = torch.cat([r.reshape(-1) for r in g["raw"]])
+    got = torch.cat([r.float().cpu().reshape(-1) for r in raws])
+    if dtype == torch.float32:
+        assert (got - want).abs().max().item() <= 1e-3
+    else:
+        assert (got.sigmoid() - want.sigmoid()).abs().max().item() <= 1e-2
+    new = model.state_dict()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    for k, v in g["stats"].items():
+        if k.endswith("num_batches_tracked"):
+            assert int(new[k]) == 1, k
+        else:
+            assert torch.allclose(new[k].float().cpu(), v, rtol=tol, atol=tol * 0.1), (k, (new[k].float().cpu() - v).abs().max())
+    model.eval()                                  # and the eval forward afterwards uses the UPDATED statistics
+    with torch.no_grad():
+        pred, _ = model(rgb.to(dev), ir.to(dev))
+    sd2 = {k: v.float().cpu() for k, v in model.state_dict().items()}
+    want_pred, _ = OracleModel(cfg)(sd2, rgb, ir)
+    if dtype == torch.float32:
+        assert torch.allclose(pred.cpu(), want_pred, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_dropout_kernel_statistics(dev):
+    from msod_amd import ops
+    ops.manual_dropout_seed(123)
+    x = torch.ones(1 << 20, device=dev)
+    y = ops.dropout_(x.clone(), 0.1)
+    torch.cuda.synchronize()
+    kept = (y != 0).float().mean().item()
+    assert abs(kept - 0.9) < 2e-3                                   # 1M Bernoulli(0.9): sigma = 3e-4
+    assert torch.allclose(y[y != 0], torch.full((1,), 1 / 0.9, device=dev))
+    assert abs(y.mean().item() - 1.0) < 3e-3                        # expectation preserved
+    z = ops.dropout_(x.clone(), 0.1)                                # next call: a different mask
+    assert (z != y).float().mean().item() > 0.1
+    ops.manual_dropout_seed(123)
+    y2 = ops.dropout_(x.clone(), 0.1)                               # same seed, same call index: the same mask
+    assert torch.equal(y, y2)
+    h = ops.dropout_(torch.ones(1 << 16, device=dev, dtype=torch.float16), 0.5)
+    assert abs((h != 0).float().mean().item() - 0.5) < 1e-2 and float(h.max()) == 2.0
+    assert torch.equal(ops.dropout_(x.clone(), 0.0), x)
+
+
+@pytest.mark.gpu
+def test_gpt_dropout_in_training_mode(dev):
+    """With the yaml's default pdrop = 0.1 the training forward of a GPT block is a random function of the seed whose
+    mean over seeds approaches the p = 0 output (dropout is unbiased), and eval mode ignores it."""
+    from msod_amd import ops
+    from msod_amd.models.common import GPT
+    torch.manual_seed(0)
+    gpt = GPT(64).to(dev)
+    with torch.no_grad():
+        gpt.pos_emb.normal_(0, 0.2)
+    rgb = ops.to_nhwc(torch.randn(2, 64, 16, 16, device=dev), torch.float32)
+    ir = ops.to_nhwc(torch.randn(2, 64, 16, 16, device=dev), torch.float32)
+
+    def run():
+        with torch.no_grad():
+            a, b = gpt([rgb, ir])
+        return a.materialize().float()
+
+    gpt.eval()
+    base = run()
+    assert torch.equal(base, run())
+    gpt.train()
+    ops.manual_dropout_seed(1)
+    t1 = run()
+    ops.manual_dropout_seed(1)
+    assert torch.equal(t1, run())                                   # reproducible for a given seed
+    ops.manual_dropout_seed(2)
+    assert not torch.equal(t1, run())
+    acc = torch.zeros_like(base)
+    n = 48
+    for s in range(n):
+        ops.manual_dropout_seed(100 + s)
+        acc += run()
+    dev_single = (t1 - base).abs().mean().item()
+    dev_mean = (acc / n - base).abs().mean().item()
+    assert dev_single > 1e-3 and dev_mean < 0.45 * dev_single       # averaging over masks converges towards the p = 0 output
+    for m in gpt.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    assert torch.allclose(run(), base, rtol=1e-5, atol=1e-5)        # p = 0 training == eval (GPT has no BatchNorm)
