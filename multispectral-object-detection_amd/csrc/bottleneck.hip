@@ -258,7 +258,7 @@ struct Bneck128Params {
   const float* b2;
   unsigned char* y;
   int ldx, xoff, ldy, yoff, kpad1, kpad2;
-  int H, W, tiles_x, tiles_y, shortcut;
+  int H, W, tiles_x, tiles_y, ntiles, shortcut;
 };
 
 template <typename T, int ABL = 0>
@@ -267,138 +267,189 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
   constexpr int NRT = (NPIX + 15) / 16;                             // 21 row tiles of the patch
   constexpr int PLANE = NRT * 16 * 128;                             // one 64-channel plane of the t patch (43008 B)
   constexpr int RING = 16384;                                       // one K tile of weights: 128 rows x 128 B
-  constexpr int NKT = 2 + 18;                                       // W1 (2) + W2 (9 taps x 2 channel halves)
+  constexpr int NBUF = 4;                                           // ring depth: three K tiles ahead of the compute tile
+  constexpr int NKT = 2 + 18;                                       // per pixel tile: W1 (2) + W2 (9 taps x 2 channel halves)
   constexpr int SLD = 64 + 4;
+  constexpr int XTRA = 12;                                          // prefetch requests issued at the head of the 3x3 loop
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sT = smem;                    // [2][NRT*16][128 B]; re-used for the epilogue strips
-  unsigned char* sR = smem + 2 * PLANE;        // [3][128][128 B]
+  unsigned char* sR = smem + 2 * PLANE;        // [NBUF][128][128 B]
+  float* sB1 = reinterpret_cast<float*>(smem + 2 * PLANE + NBUF * RING);   // [128] bias of the 1x1 conv
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int grp = wave >> 2;                   // stagger group (waves w, w + 4 share a SIMD)
-  const int wmr = wave >> 1, wnc = wave & 1;   // main loop: tile rows 4 wmr .. +4, channels 64 wnc .. +64
+  const int wmr = wave >> 1, wnc = wave & 1;   // 3x3 loop: tile rows 4 wmr .. +4, channels 64 wnc .. +64
   const int tiles = p.tiles_x * p.tiles_y;
-  const int b = blockIdx.x / tiles, tt = blockIdx.x - b * tiles;
-  const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
-  const int y0 = ty * TS, x0 = tx * TS;
-  const long img_pix = (long)b * p.H * p.W;
+  if (tid < C) sB1[tid] = p.b1 != nullptr ? p.b1[tid] : 0.0f;     // (a global load inside the tile loop would drain the DMA ring)
+  float b2v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b2v[j] = p.b2 != nullptr ? p.b2[wnc * 64 + j * 16 + lrow] : 0.0f;
+  const int my_tiles = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // this workgroup walks tiles bid, bid + grid, ...
   const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(cft_zero_page_b);
 
-  // ---- x fragments of the halo patch: row tile rt = wave + 8 it, lane = (pixel lrow, k-group lgrp), 4 k chunks of 32
-  gran_t a1[3][4];
-  bool inside[3];
-#pragma unroll
-  for (int it = 0; it < 3; ++it) {
-    const int q = (wave + it * 8) * 16 + lrow;
-    const int py = q / PW, px = q - py * PW;
-    const int zy = y0 - 1 + py, zx = x0 - 1 + px;
-    inside[it] = q < NPIX && (unsigned)zy < (unsigned)p.H && (unsigned)zx < (unsigned)p.W;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      gran_t t = {0u, 0u, 0u, 0u};
-      if (inside[it]) t = *reinterpret_cast<const gran_t*>(p.x + ((img_pix + (long)zy * p.W + zx) * p.ldx + p.xoff + ks * 32 + lgrp * 8) * 2);
-      a1[it][ks] = t;
-    }
-  }
-
-  // ---- weight ring: K tile kt = rows n (128) x 64 k; this thread stages rows r0 and r0 + 64, k-granule g
+  // ---- weight ring: K tile = rows n (128) x 64 k; this thread stages rows r0 and r0 + 64, k-granule g.  The stream of
+  // K tiles is W1.k0 W1.k1 W2.(tap,half) x 18, repeated for every pixel tile of this workgroup (zero page afterwards).
   const int r0 = tid >> 3, slot_s = tid & 7, g = slot_s ^ (r0 & 7);
-  int st_kt = 0, sb = 0;
+  int st_kt = 0, st_left = my_tiles, sb = 0;
 #define BN128_STAGE(part_)                                                                               \
   {                                                                                                      \
     const int n_ = r0 + 64 * (part_);                                                                    \
     const unsigned char* src_;                                                                           \
-    if (st_kt < 2) src_ = p.w1 + ((long)n_ * p.kpad1 + st_kt * 64 + g * 8) * 2;                          \
-    else if (st_kt < NKT) src_ = p.w2 + ((long)n_ * p.kpad2 + (st_kt - 2) * 64 + g * 8) * 2;             \
-    else src_ = zero_page;                                                                               \
+    if (st_left <= 0) src_ = zero_page;                                                                  \
+    else if (st_kt < 2) src_ = p.w1 + ((long)n_ * p.kpad1 + st_kt * 64 + g * 8) * 2;                     \
+    else src_ = p.w2 + ((long)n_ * p.kpad2 + (st_kt - 2) * 64 + g * 8) * 2;                              \
     if constexpr (!(ABL & 8))                                                                            \
       __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(sR + sb * RING + (part_) * 8192 + wave * 1024), 16, 0, 0); \
-    if ((part_) == 1) { ++st_kt; sb = sb == 2 ? 0 : sb + 1; }                                            \
+    if ((part_) == 1) {                                                                                  \
+      sb = sb == NBUF - 1 ? 0 : sb + 1;                                                                  \
+      if (++st_kt == NKT) { st_kt = 0; --st_left; }                                                      \
+    }                                                                                                    \
   }
 #define BN128_BARRIER() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+
+  // ---- x fragments of a tile's halo patch: row tile rt = wave + 8 it, lane = (pixel lrow, k-group lgrp), 4 k chunks of 32
+  // The fragments of the NEXT tile are requested into a1n while the current tile's 3x3 loop runs and handed over to a1
+  // after it, so that no global-load destination is live across the DMA ring's counted waits (hipcc drains vmcnt to 0
+  // at the first use of a pending load result: that first use is the single hand-over point below).
+  gran_t a1[3][4], a1n[3][4];
+  uint32_t inside = 0, inside_n = 0;   // bit it: this lane's patch pixel of row tile it lies in the image
+#define BN128_FETCH_X(tile_)                                                                             \
+  {                                                                                                      \
+    const int b_ = (tile_) / tiles, tt_ = (tile_) - b_ * tiles;                                          \
+    const int ty_ = tt_ / p.tiles_x, tx_ = tt_ - ty_ * p.tiles_x;                                        \
+    const long ip_ = (long)b_ * p.H * p.W;                                                               \
+    inside_n = 0;                                                                                        \
+    _Pragma("unroll") for (int it = 0; it < 3; ++it) {                                                   \
+      const int q = (wave + it * 8) * 16 + lrow;                                                         \
+      const int py = q / PW, px = q - py * PW;                                                           \
+      const int zy = ty_ * TS - 1 + py, zx = tx_ * TS - 1 + px;                                          \
+      const bool in_ = (tile_) >= 0 && q < NPIX && (unsigned)zy < (unsigned)p.H && (unsigned)zx < (unsigned)p.W; \
+      inside_n |= (in_ ? 1u : 0u) << it;                                                                 \
+      /* always exactly 12 loads per wave (the counted waits of the 3x3 loop rely on it): outside pixels read the zero page */ \
+      const unsigned char* px_ = in_ ? p.x + ((ip_ + (long)zy * p.W + zx) * p.ldx + p.xoff + lgrp * 8) * 2 : zero_page; \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                   \
+        a1n[it][ks] = *reinterpret_cast<const gran_t*>(px_ + (in_ ? ks * 64 : 0));                       \
+    }                                                                                                    \
+  }
+#define BN128_HANDOVER()                                                                                 \
+  {                                                                                                      \
+    _Pragma("unroll") for (int it = 0; it < 3; ++it)                                                     \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                 \
+        asm volatile("" : "+v"(a1n[it][ks]));   /* a real use: the load has landed from here on */       \
+        a1[it][ks] = a1n[it][ks];                                                                        \
+      }                                                                                                  \
+    inside = inside_n;                                                                                   \
+  }
+  BN128_FETCH_X((int)blockIdx.x)
   BN128_STAGE(0) BN128_STAGE(1)
   BN128_STAGE(0) BN128_STAGE(1)
-  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // K tile 0 (and the older x fragments) landed
+  BN128_STAGE(0) BN128_STAGE(1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // K tiles 0-2, the x fragments, the biases: everything landed
+  BN128_HANDOVER()
   BN128_BARRIER()
-  if (grp == 1) BN128_BARRIER()
 
-  // ---- t^T = W1 x^T on the patch: two K tiles, two phases each (output channels 0-63 / 64-127)
   const int fb = lrow * 128 + ((lgrp ^ (lrow & 7)) << 4);          // fragment read base inside a ring buffer (row lrow)
-  int cb = 0;
-  f32x4_t acc1[3][8];
-#pragma unroll
-  for (int it = 0; it < 3; ++it)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc1[it][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-    for (int ph = 0; ph < 2; ++ph) {
-      gran_t wf[4][2];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int j = ph * 4 + jj;
-        wf[jj][0] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + fb);
-        wf[jj][1] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + (fb ^ 64));
-      }
-      BN128_STAGE(ph)
-      if (ph == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      BN128_BARRIER()
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int it = 0; it < 3; ++it)
-          if (wave + it * 8 < NRT) {   // wave-uniform
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-              if constexpr (!(ABL & 1)) acc1[it][ph * 4 + jj] = mma_granule<T>(wf[jj][ks], a1[it][kt * 2 + ks], acc1[it][ph * 4 + jj]);
-          }
-      __builtin_amdgcn_s_setprio(0);
-      BN128_BARRIER()
-    }
-    cb = cb == 2 ? 0 : cb + 1;
-  }
-  if (grp == 0) BN128_BARRIER()                // both groups aligned again
-  // bias + SiLU -> 16-bit -> t patch (zero outside the image: the 3x3 conv's padding)
-#pragma unroll
-  for (int it = 0; it < 3; ++it) {
-    const int rt = wave + it * 8;
-    if (rt < NRT) {
-      const int q = rt * 16 + lrow;
-      const uint32_t keep = inside[it] ? 0xffffffffu : 0u;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c0 = j * 16 + lgrp * 4;        // first of this lane's 4 channels
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (ABL & 1) ? 0.0f : apply_act<CFT_ACT_SILU>(acc1[it][j][e] + (p.b1 != nullptr ? p.b1[c0 + e] : 0.0f));
-        uint2 w;
-        w.x = Elem<T>::pack2(v[0], v[1]) & keep;
-        w.y = Elem<T>::pack2(v[2], v[3]) & keep;
-        const int cc = c0 & 63;
-        *reinterpret_cast<uint2*>(sT + (c0 >> 6) * PLANE + q * 128 + ((((cc >> 3) ^ (q & 7)) << 4) | ((cc & 7) << 1))) = w;
-      }
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  BN128_BARRIER()                                // the whole t patch is visible
-  if (grp == 1) BN128_BARRIER()                  // stagger again
-
-  // ---- 3x3 conv of the t patch: 18 K tiles (tap, channel half), two phases (tile rows 4 wmr + {0,1} / {2,3})
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int fbn = (wnc * 64 + lrow) * 128 + ((lgrp ^ (lrow & 7)) << 4);
+  int cb = 0;
+  float* stage = reinterpret_cast<float*>(sT) + wave * (16 * SLD);
+  const uint32_t t_lds = (uint32_t)(uintptr_t)(lds_void_t*)sT;    // LDS byte address of the t patch
+
 #pragma unroll 1
-  for (int kk = 0; kk < 18; ++kk) {
-    const int tap = kk >> 1, half = kk & 1;
-    const int kh = tap / 3, kw = tap - kh * 3;
-    const int qb = (wmr * 4 + kh) * PW + kw + lrow;      // patch pixel of tile row 4 wmr, this lane's column, this tap
-    gran_t af[2][2], bf[4][2];
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    const int tile = (int)blockIdx.x + ti * (int)gridDim.x;
+    const int b = tile / tiles, tt = tile - b * tiles;
+    const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+    const int y0 = ty * TS, x0 = tx * TS;
+    const long img_pix = (long)b * p.H * p.W;
+    const uint32_t inside_cur = inside;
+    if (grp == 1) BN128_BARRIER()              // group 1 runs one barrier behind group 0
+
+    // ---- t^T = W1 x^T on the patch: two K tiles, two phases each (output channels 0-63 / 64-127)
+    f32x4_t acc1[3][8];
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc1[it][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      gran_t wf[8][2];      // all W1 fragments of this K tile are read in its FIRST phase (like the 3x3 loop's B fragments):
+                            // the ring buffer is re-staged three K tiles later, >= 2 phases after its last read by either group
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        if (ph == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            wf[j][0] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + fb);
+            wf[j][1] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + (fb ^ 64));
+          }
+        }
+        BN128_STAGE(ph)                        // (K tiles 0-2 of this pixel tile landed before the loop / at the hand-over)
+        BN128_BARRIER()
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int it = 0; it < 3; ++it)
+            if (wave + it * 8 < NRT) {   // wave-uniform
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj)
+                if constexpr (!(ABL & 1)) acc1[it][ph * 4 + jj] = mma_granule<T>(wf[ph * 4 + jj][ks], a1[it][kt * 2 + ks], acc1[it][ph * 4 + jj]);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        BN128_BARRIER()
+      }
+      cb = cb == NBUF - 1 ? 0 : cb + 1;
+    }
+    if (grp == 0) BN128_BARRIER()                // both groups aligned again
+    // bias + SiLU -> 16-bit -> t patch (zero outside the image: the 3x3 conv's padding)
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int rt = wave + it * 8;
+      if (rt < NRT) {
+        const int q = rt * 16 + lrow;
+        const uint32_t keep = ((inside_cur >> it) & 1u) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c0 = j * 16 + lgrp * 4;        // first of this lane's 4 channels
+          float v[4];
+          const f32x4_t b1q = *reinterpret_cast<const f32x4_t*>(sB1 + c0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (ABL & 1) ? 0.0f : apply_act<CFT_ACT_SILU>(acc1[it][j][e] + b1q[e]);
+          uint2 w;
+          w.x = Elem<T>::pack2(v[0], v[1]) & keep;
+          w.y = Elem<T>::pack2(v[2], v[3]) & keep;
+          const int cc = c0 & 63;
+          // (inline asm: for a compiler-visible LDS store hipcc first drains vmcnt to 0 - the LDS-DMA ring could alias it)
+          const uint32_t ta = t_lds + (c0 >> 6) * PLANE + q * 128 + ((((cc >> 3) ^ (q & 7)) << 4) | ((cc & 7) << 1));
+          const unsigned long long wq = ((unsigned long long)w.y << 32) | w.x;
+          asm volatile("ds_write_b64 %0, %1" ::"v"(ta), "v"(wq) : "memory");
+        }
+      }
+    }
+    // requests that land under the 3x3 loop: the NEXT tile's x fragments (ALWAYS issued, 12 per wave - masked ones
+    // read the zero page - because the counted vmcnt of the first two K tiles below allows for exactly that many)
+    {
+      const int nt_ = tile + (int)gridDim.x;
+      BN128_FETCH_X(nt_ < p.ntiles ? nt_ : -1)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BN128_BARRIER()                                // the whole t patch is visible
+    if (grp == 1) BN128_BARRIER()                  // stagger again
+
+    // ---- 3x3 conv of the t patch: 18 K tiles (tap, channel half), two phases (tile rows 4 wmr + {0,1} / {2,3})
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kk = 0; kk < 18; ++kk) {
+      const int tap = kk >> 1, half = kk & 1;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const int qb = (wmr * 4 + kh) * PW + kw + lrow;      // patch pixel of tile row 4 wmr, this lane's column, this tap
+      gran_t af[2][2], bf[4][2];
 #define BN128_READ_A(i0_)                                                                                \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
     const int q = qb + ((i0_) + i) * PW;                                                                 \
@@ -417,48 +468,34 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
         }                                                                                                \
     __builtin_amdgcn_s_setprio(0);                                                                       \
   }
-    // phase 1
-    BN128_READ_A(0)
+      // phase 1
+      BN128_READ_A(0)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      bf[j][0] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + fbn);
-      bf[j][1] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + (fbn ^ 64));
+      for (int j = 0; j < 4; ++j) {
+        bf[j][0] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + fbn);
+        bf[j][1] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + (fbn ^ 64));
+      }
+      BN128_STAGE(0)
+      BN128_BARRIER()
+      BN128_MMA(0)
+      BN128_BARRIER()
+      // phase 2; the wait covers the next K tile.  During the first two K tiles the prefetch requests issued just before
+      // the loop (x fragments of the next pixel tile, shortcut vectors) may still be in flight behind it.
+      BN128_READ_A(2)
+      BN128_STAGE(1)
+      if (kk < 2) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XTRA) : "memory"); }
+      else { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      BN128_BARRIER()
+      BN128_MMA(2)
+      BN128_BARRIER()
+      cb = cb == NBUF - 1 ? 0 : cb + 1;
     }
-    BN128_STAGE(0)
-    BN128_BARRIER()
-    BN128_MMA(0)
-    BN128_BARRIER()
-    // phase 2
-    BN128_READ_A(2)
-    BN128_STAGE(1)
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    BN128_BARRIER()
-    BN128_MMA(2)
-    BN128_BARRIER()
-    cb = cb == 2 ? 0 : cb + 1;
-  }
 #undef BN128_READ_A
 #undef BN128_MMA
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-page tiles staged past the last K tile
-  if (grp == 0) BN128_BARRIER()
-  BN128_BARRIER()                                     // nobody reads the t patch any more: the strips may overwrite it
-#undef BN128_STAGE
-#undef BN128_BARRIER
-
-  // ---- epilogue: bias + SiLU -> strip -> (+ shortcut) -> 16-bit rows; strip i = tile row 4 wmr + i, 16 pixels x 64 channels
-  if constexpr (ABL & 4) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-    return;
-  }
-  float* stage = reinterpret_cast<float*>(sT) + wave * (16 * SLD);
-  float b2v[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) b2v[j] = p.b2 != nullptr ? p.b2[wnc * 64 + j * 16 + lrow] : 0.0f;
-  gran_t rs[4][2];
-  if (p.shortcut) {          // shortcut vectors of all four strips, requested up front (L2 hits: the patch was just read)
+    // hand-over point: this tile's shortcut vectors are requested (L2 hits: the patch was read a few microseconds ago;
+    // holding them in registers through the 3x3 loop would spill) and the next tile's x fragments are consumed, hipcc
+    // waits vmcnt(0) for both - which also lands the first three K tiles of the next pixel tile
+    gran_t rs[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -466,44 +503,66 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
         const int it = lane + v * 64;
         const int row = it >> 3, col = (it & 7) * 8;
         const int x = x0 + row, y = y0 + wmr * 4 + i;
-        gran_t t = {0u, 0u, 0u, 0u};
-        if (x < p.W && y < p.H)
-          t = *reinterpret_cast<const gran_t*>(p.x + ((img_pix + (long)y * p.W + x) * p.ldx + p.xoff + wnc * 64 + col) * 2);
-        rs[i][v] = t;
+        const unsigned char* rp_ = (p.shortcut && x < p.W && y < p.H)
+            ? p.x + ((img_pix + (long)y * p.W + x) * p.ldx + p.xoff + wnc * 64 + col) * 2 : zero_page;
+        rs[i][v] = *reinterpret_cast<const gran_t*>(rp_);
       }
-  }
+    BN128_HANDOVER()
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(rs[i][0])); asm volatile("" : "+v"(rs[i][1])); }
+    if (grp == 0) BN128_BARRIER()
+    BN128_BARRIER()                                     // nobody reads the t patch any more: the strips may overwrite it
+
+    // ---- epilogue: bias + SiLU -> strip -> (+ shortcut) -> 16-bit rows; strip i = tile row 4 wmr + i, 16 pixels x 64 channels
+    if constexpr (ABL & 4) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        stage[(lgrp * 4 + e) * SLD + j * 16 + lrow] = apply_act<CFT_ACT_SILU>(acc[i][j][e] + b2v[j]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      const int it = lane + v * 64;
-      const int row = it >> 3, col = (it & 7) * 8;
-      const int x = x0 + row, y = y0 + wmr * 4 + i;
-      if (x < p.W && y < p.H) {
-        const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col);
-        const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col + 4);
-        float o[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-        if (p.shortcut) {
-          float rf[8];
-          Elem<T>::unpack(rs[i][v], rf);
+      for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(rs[i][0]), "v"(rs[i][1]));
+    } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] += rf[e];
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            stage[(lgrp * 4 + e) * SLD + j * 16 + lrow] = apply_act<CFT_ACT_SILU>(acc[i][j][e] + b2v[j]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const int it = lane + v * 64;
+          const int row = it >> 3, col = (it & 7) * 8;
+          const int x = x0 + row, y = y0 + wmr * 4 + i;
+          if (x < p.W && y < p.H) {
+            const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col);
+            const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col + 4);
+            float o[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            if (p.shortcut) {
+              float rf[8];
+              Elem<T>::unpack(rs[i][v], rf);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] += rf[e];
+            }
+            *reinterpret_cast<gran_t*>(p.y + ((img_pix + (long)y * p.W + x) * p.ldy + p.yoff + wnc * 64 + col) * 2) = Elem<T>::pack(o);
+          }
         }
-        *reinterpret_cast<gran_t*>(p.y + ((img_pix + (long)y * p.W + x) * p.ldy + p.yoff + wnc * 64 + col) * 2) = Elem<T>::pack(o);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BN128_BARRIER()                                     // strips are dead before the next tile's t patch is written
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero-page K tiles staged past the last one
+#undef BN128_STAGE
+#undef BN128_BARRIER
+#undef BN128_FETCH_X
+#undef BN128_HANDOVER
 }
 
 extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, int kpad1, const float* b1,
@@ -533,8 +592,15 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
     q.ldx = ldx; q.xoff = xoff; q.ldy = ldy; q.yoff = yoff; q.kpad1 = kpad1; q.kpad2 = kpad2;
     q.H = H; q.W = W; q.tiles_x = (W + 15) / 16; q.tiles_y = (H + 15) / 16; q.shortcut = shortcut ? 1 : 0;
     CFT_REQUIRE((long)B * q.tiles_x * q.tiles_y < (1L << 31), "cft_bottleneck: too many tiles");
-    constexpr int smem128 = 2 * 21 * 16 * 128 + 3 * 16384;
-    const dim3 grid128(B * q.tiles_x * q.tiles_y), block128(512);
+    q.ntiles = B * q.tiles_x * q.tiles_y;
+    constexpr int smem128 = 2 * 21 * 16 * 128 + 4 * 16384 + 512;
+    int cus = 256;
+    {   // persistent: one workgroup per CU (148 KiB LDS each) walks tiles bid, bid + grid, ...
+      static int cached = 0;
+      if (!cached) { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached = prop.multiProcessorCount; else cached = 256; }
+      cus = cached;
+    }
+    const dim3 grid128(q.ntiles < cus ? q.ntiles : cus), block128(512);
     hipStream_t s128 = as_stream(stream);
 #define BN128_LAUNCH(T_, ABL_)                                                                    \
     {                                                                                             \
