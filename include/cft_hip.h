@@ -73,6 +73,9 @@ int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, int kpad1, 
                    const void* w2, int kpad2, const float* b2, void* y, int ldy, int yoff,
                    int B, int H, int W, int c, int shortcut, int dtype, void* stream);
 
+/* Timing probes (tools/bneck_probe.py): device buffer that the variant-932 Bottleneck kernel fills with cycle stamps. */
+int cft_set_debug_buffer(void* p);
+
 /* Tuning knob: force one tile configuration of cft_conv2d (0 = automatic, the default; see
  * csrc/conv_gemm.hip for the table).  Returns the previous value.  Not needed for normal use. */
 int cft_set_conv_variant(int variant);
@@ -130,6 +133,17 @@ int cft_copy_channels(const void* in, int ldi, int ioff, void* out, int ldo, int
  */
 int cft_to_nhwc(const void* in, int in_dtype, long stride_b, long stride_c, long stride_h, long stride_w,
                 void* out, int ldo, int ooff, int B, int C, int cpad, int H, int W, int dtype, void* stream);
+
+/*
+ * Letterbox on the device (utils/datasets.py:1698-1728 `letterbox`: cv2.resize(INTER_LINEAR) to resized_w x resized_h,
+ * then cv2.copyMakeBorder with a constant colour), 8-bit 3-channel images.  src: HWC, row stride in bytes; dst element
+ * (y, x, c) at dst + y*stride_y + x*stride_x + c'*stride_c with c' = flip_channels ? 2 - c : c - strides (w*3, 3, 1) give
+ * cv2's HWC image, (w, 1, h*w) with flip = 1 gives the CHW RGB plane the callers build next (datasets.py:1276-1281).
+ * The geometry (resized size, top/left) is computed by the caller exactly as the reference does; colour = border value.
+ */
+int cft_letterbox_u8(const unsigned char* src, int src_h, int src_w, long src_row_stride,
+                     unsigned char* dst, int dst_h, int dst_w, long dst_stride_y, long dst_stride_x, long dst_stride_c, int flip_channels,
+                     int resized_h, int resized_w, int top, int left, int color0, int color1, int color2, void* stream);
 
 /* Elementwise out = a + b over M pixels x C channels (Add / Add2, models/common.py:228-243). */
 int cft_add(const void* a, int lda, int aoff, const void* b, int ldb, int boff,

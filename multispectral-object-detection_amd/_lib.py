@@ -30,10 +30,12 @@ SIGNATURES = {
     "cft_device_check": [],
     "cft_conv2d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_set_conv_variant": [_i],
+    "cft_set_debug_buffer": [_vp],
     "cft_bottleneck": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_focus_s2d": [_vp, _vp, _i, _i, _i, _i, _vp],
     "cft_focus_s2d_u8": [_vp, _l, _l, _l, _vp, _i, _i, _i, _f, _i, _vp],
     "cft_focus_conv": [_vp, _i, _l, _l, _l, _f, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_letterbox_u8": [_vp, _i, _i, _l, _vp, _i, _i, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_to_nhwc": [_vp, _i, _l, _l, _l, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_spp_maxpool": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_copy_channels": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

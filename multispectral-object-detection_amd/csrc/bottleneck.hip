@@ -250,6 +250,9 @@ __global__ void __launch_bounds__(512) bottleneck_kernel(const BneckParams p) {
 //     operand so a lane ends up with 4 consecutive channels of one pixel (8-byte LDS writes), zero outside the image.
 //   * epilogue: bias + SiLU -> fp32 strip (aliases the dead t patch) -> 16-byte row vectors -> + shortcut -> 16-bit stores.
 // Every product, the 32-wide k chunks, their order and every rounding are those of the two-launch path: bit-identical.
+static unsigned long long* g_bneck_dbg = nullptr;
+extern "C" int cft_set_debug_buffer(void* p) { g_bneck_dbg = (unsigned long long*)p; return CFT_OK; }   // timing probes only
+
 struct Bneck128Params {
   const unsigned char* x;
   const unsigned char* w1;   // [128][kpad1]
@@ -259,6 +262,7 @@ struct Bneck128Params {
   unsigned char* y;
   int ldx, xoff, ldy, yoff, kpad1, kpad2;
   int H, W, tiles_x, tiles_y, ntiles, shortcut;
+  unsigned long long* dbg;   // timing probe (variant 932): [workgroup][wave 0 / 4][tile][8] s_memtime stamps
 };
 
 template <typename T, int ABL = 0>
@@ -364,6 +368,12 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
     const int y0 = ty * TS, x0 = tx * TS;
     const long img_pix = (long)b * p.H * p.W;
     const uint32_t inside_cur = inside;
+#define BN128_STAMP(k_)                                                                                  \
+    if constexpr (ABL & 32) {                                                                            \
+      if (p.dbg != nullptr && lane == 0 && (wave & 3) == 0 && ti < 8)                                    \
+        p.dbg[(((long)blockIdx.x * 2 + grp) * 8 + ti) * 8 + (k_)] = __builtin_readcyclecounter();        \
+    }
+    BN128_STAMP(0)
     if (grp == 1) BN128_BARRIER()              // group 1 runs one barrier behind group 0
 
     // ---- t^T = W1 x^T on the patch: two K tiles, two phases each (output channels 0-63 / 64-127)
@@ -402,6 +412,7 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
       }
       cb = cb == NBUF - 1 ? 0 : cb + 1;
     }
+    BN128_STAMP(1)
     if (grp == 0) BN128_BARRIER()                // both groups aligned again
     // bias + SiLU -> 16-bit -> t patch (zero outside the image: the 3x3 conv's padding)
 #pragma unroll
@@ -435,6 +446,7 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
       BN128_FETCH_X(nt_ < p.ntiles ? nt_ : -1)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BN128_STAMP(2)
     BN128_BARRIER()                                // the whole t patch is visible
     if (grp == 1) BN128_BARRIER()                  // stagger again
 
@@ -489,7 +501,9 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
       BN128_MMA(2)
       BN128_BARRIER()
       cb = cb == NBUF - 1 ? 0 : cb + 1;
+      if (kk == 2) BN128_STAMP(3)
     }
+    BN128_STAMP(4)
 #undef BN128_READ_A
 #undef BN128_MMA
     // hand-over point: this tile's shortcut vectors are requested (L2 hits: the patch was read a few microseconds ago;
@@ -510,6 +524,7 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
     BN128_HANDOVER()
 #pragma unroll
     for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(rs[i][0])); asm volatile("" : "+v"(rs[i][1])); }
+    BN128_STAMP(5)
     if (grp == 0) BN128_BARRIER()
     BN128_BARRIER()                                     // nobody reads the t patch any more: the strips may overwrite it
 
@@ -556,8 +571,11 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BN128_STAMP(6)
     BN128_BARRIER()                                     // strips are dead before the next tile's t patch is written
+    BN128_STAMP(7)
   }
+#undef BN128_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero-page K tiles staged past the last one
 #undef BN128_STAGE
 #undef BN128_BARRIER
@@ -593,6 +611,7 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
     q.H = H; q.W = W; q.tiles_x = (W + 15) / 16; q.tiles_y = (H + 15) / 16; q.shortcut = shortcut ? 1 : 0;
     CFT_REQUIRE((long)B * q.tiles_x * q.tiles_y < (1L << 31), "cft_bottleneck: too many tiles");
     q.ntiles = B * q.tiles_x * q.tiles_y;
+    q.dbg = g_bneck_dbg;
     constexpr int smem128 = 2 * 21 * 16 * 128 + 4 * 16384 + 512;
     int cus = 256;
     {   // persistent: one workgroup per CU (148 KiB LDS each) walks tiles bid, bid + grid, ...
@@ -615,6 +634,7 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
         case 902: BN128_LAUNCH(uint16_t, 2) break;
         case 904: BN128_LAUNCH(uint16_t, 4) break;
         case 908: BN128_LAUNCH(uint16_t, 8) break;
+        case 932: BN128_LAUNCH(uint16_t, 32) break;
         default: BN128_LAUNCH(uint16_t, 0) break;
       }
     }

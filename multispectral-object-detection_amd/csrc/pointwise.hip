@@ -577,3 +577,77 @@ extern "C" int cft_detect_decode(const float* logits, int ldl, float* raw, float
                      B, ny, nx, na, no, stride, row0, total_rows);
   return cft_check_launch("detect_decode_kernel");
 }
+
+// ------------------------------------------------------------------------------- letterbox
+// Caller-side pre-processing one step before the hot path (reference utils/datasets.py:1698-1728):
+// resize an 8-bit HWC image to `new_unpad` with cv2.INTER_LINEAR and pad it to the letterboxed shape with a constant
+// colour, in ONE pass on the device.  The resize restates OpenCV's published 8-bit bilinear path (resize.cpp,
+// INTER_RESIZE_COEF_BITS = 11): source coordinate fx = (float)((dx + 0.5) * scale - 0.5) with scale = 1 / (dst / src) in
+// double, coefficients rounded to 1/2048, horizontal pass in int, vertical pass
+// ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.  cv2 is a third-party dependency that is absent from this
+// image (and unpinned by the reference): that part is "parity unpinned"; the geometry is the reference's own code.
+// The destination is addressed through element strides (y, x, c) and an optional channel flip, so the same kernel writes
+// cv2's HWC BGR image or directly the CHW RGB plane of a [B,6,H,W] batch (the `img[:, :, ::-1].transpose(2, 0, 1)` of
+// utils/datasets.py:1276-1281).
+__device__ __forceinline__ int cft_cv_round(float v) { return __float2int_rn(v); }   // cvRound: nearest, ties to even
+
+__global__ void __launch_bounds__(256) letterbox_u8_kernel(const unsigned char* __restrict__ src, int sh, int sw, long src_row_stride,
+                                                           unsigned char* __restrict__ dst, int dh, int dw, long dsy, long dsx, long dsc, int flip,
+                                                           int rh, int rw, int top, int left, int c0, int c1, int c2) {
+  const long total = (long)dh * dw;
+  const double scale_x = 1.0 / ((double)rw / (double)sw), scale_y = 1.0 / ((double)rh / (double)sh);
+  const bool resize = rh != sh || rw != sw;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int y = (int)(idx / dw), x = (int)(idx - (long)y * dw);
+    const int ry = y - top, rx = x - left;
+    int v[3] = {c0, c1, c2};
+    if (ry >= 0 && ry < rh && rx >= 0 && rx < rw) {
+      if (!resize) {
+        const unsigned char* s = src + (long)ry * src_row_stride + rx * 3L;
+        v[0] = s[0]; v[1] = s[1]; v[2] = s[2];
+      } else {
+        float fx = (float)(((double)rx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= (float)sx;
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; }
+        float fy = (float)(((double)ry + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        // cv2 clamps rows by index (sy0 = clip(sy), sy1 = clip(sy + 1)) and keeps the fractional weights
+        const int sy0 = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+        const int sy1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
+        const int a0 = cft_cv_round((1.f - fx) * 2048.f), a1 = cft_cv_round(fx * 2048.f);
+        const int b0 = cft_cv_round((1.f - fy) * 2048.f), b1 = cft_cv_round(fy * 2048.f);
+        const int sx1 = sx + 1 > sw - 1 ? sw - 1 : sx + 1;
+        const unsigned char* r0 = src + (long)sy0 * src_row_stride;
+        const unsigned char* r1 = src + (long)sy1 * src_row_stride;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int h0 = r0[sx * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
+          const int h1 = r1[sx * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+          v[c] = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      int o = v[c];
+      o = o < 0 ? 0 : (o > 255 ? 255 : o);
+      dst[(long)y * dsy + (long)x * dsx + (long)(flip ? 2 - c : c) * dsc] = (unsigned char)o;
+    }
+  }
+}
+
+extern "C" int cft_letterbox_u8(const unsigned char* src, int src_h, int src_w, long src_row_stride,
+                                unsigned char* dst, int dst_h, int dst_w, long dst_stride_y, long dst_stride_x, long dst_stride_c, int flip_channels,
+                                int resized_h, int resized_w, int top, int left, int color0, int color1, int color2, void* stream) {
+  CFT_REQUIRE(src && dst, "cft_letterbox_u8: null pointer");
+  CFT_REQUIRE(src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0 && resized_h > 0 && resized_w > 0, "cft_letterbox_u8: non-positive size");
+  CFT_REQUIRE(top >= 0 && left >= 0 && top + resized_h <= dst_h && left + resized_w <= dst_w, "cft_letterbox_u8: the resized image does not fit the destination");
+  CFT_REQUIRE(src_row_stride >= 3L * src_w, "cft_letterbox_u8: bad source row stride");
+  const long total = (long)dst_h * dst_w;
+  hipLaunchKernelGGL(letterbox_u8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), src, src_h, src_w, src_row_stride,
+                     dst, dst_h, dst_w, dst_stride_y, dst_stride_x, dst_stride_c, flip_channels, resized_h, resized_w, top, left, color0, color1, color2);
+  return cft_check_launch("letterbox_u8_kernel");
+}

@@ -176,8 +176,36 @@ def make_train_golden():
     print(f"s_x3_train_96 raw {[tuple(r.shape) for r in raws]} std {raws[0].std():.3f}, {len(stats)} statistics -> {os.path.getsize(path)/1e3:.0f} kB")
 
 
+def make_letterbox_golden():
+    """The reference's own `letterbox` (utils/datasets.py:1698-1728) on seeded uint8 images; cv2 is absent, so its two
+    calls (`cv2.resize`, `cv2.copyMakeBorder`) are bound to the restatements in oracle/letterbox_oracle.py; every other
+    line executed - the geometry and the composition - is the reference's."""
+    install_reference()
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from oracle import letterbox_oracle as LO
+    cv2 = sys.modules["cv2"]
+    cv2.resize, cv2.copyMakeBorder = LO.resize, LO.copyMakeBorder
+    cv2.INTER_LINEAR, cv2.BORDER_CONSTANT = LO.INTER_LINEAR, LO.BORDER_CONSTANT
+    from utils.datasets import letterbox  # the reference
+    rng = np.random.RandomState(0)
+    cases = []
+    for (h, w), kw in [((120, 160), dict(new_shape=160)), ((128, 160), dict(new_shape=(160, 160), auto=False)),
+                       ((256, 320), dict(new_shape=160, auto=False, scaleup=False)), ((75, 50), dict(new_shape=104, stride=8)),
+                       ((50, 83), dict(new_shape=(96, 192), auto=False, scaleup=True)), ((64, 64), dict(new_shape=64)),
+                       ((37, 51), dict(new_shape=96, scaleFill=True, auto=False)), ((90, 120), dict(new_shape=64, auto=True, stride=32))]:
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        out, ratio, pad = letterbox(img, **kw)
+        cases.append({"img": torch.from_numpy(img), "kwargs": kw, "out": torch.from_numpy(np.ascontiguousarray(out)),
+                      "ratio": tuple(float(r) for r in ratio), "pad": tuple(float(p) for p in pad)})
+        print("letterbox", (h, w), kw, "->", out.shape, ratio, pad)
+    torch.save(cases, os.path.join(HERE, "letterbox_cases.pt"))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "train":
+    if len(sys.argv) > 1 and sys.argv[1] == "letterbox":
+        make_letterbox_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "train":
         make_train_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "nms":
         make_nms_golden()
@@ -188,3 +216,4 @@ if __name__ == "__main__":
         make_nms_golden()
         make_checkpoint()
         make_train_golden()
+        make_letterbox_golden()

@@ -1,0 +1,90 @@
+"""Letterbox row: the package's geometry restatement against the reference-generated golden
+(CPU), the HIP kernel against the oracle / golden (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import msod_amd  # noqa: F401
+from msod_amd.utils.datasets import letterbox_geometry
+from oracle import letterbox_oracle as LO
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = torch.load(os.path.join(HERE, "golden", "letterbox_cases.pt"), weights_only=False)
+
+
+def _oracle_letterbox(img, **kw):
+    """utils/datasets.py:1698-1728 with the package's geometry function and the oracle's cv2 restatements."""
+    color = kw.pop("color", (114, 114, 114))
+    new_unpad, ratio, pad, (top, bottom, left, right) = letterbox_geometry(img.shape[:2], **kw)
+    if img.shape[:2][::-1] != new_unpad:
+        img = LO.resize(img, new_unpad, interpolation=LO.INTER_LINEAR)
+    return LO.copyMakeBorder(img, top, bottom, left, right, LO.BORDER_CONSTANT, value=color), ratio, pad
+
+
+@pytest.mark.parametrize("i", range(len(CASES)))
+def test_geometry_and_oracle_reproduce_the_reference_letterbox(i):
+    c = CASES[i]
+    out, ratio, pad = _oracle_letterbox(c["img"].numpy(), **dict(c["kwargs"]))
+    assert out.shape == tuple(c["out"].shape) and np.array_equal(out, c["out"].numpy())
+    assert tuple(float(r) for r in ratio) == c["ratio"] and tuple(float(p) for p in pad) == c["pad"]
+
+
+def test_resize_restatement_basics():
+    img = np.arange(4 * 6 * 3, dtype=np.uint8).reshape(4, 6, 3)
+    assert np.array_equal(LO.resize(img, (6, 4)), img)                       # identity size
+    up = LO.resize(img, (12, 8))
+    assert up.shape == (8, 12, 3) and up[0, 0, 0] == img[0, 0, 0] and up[-1, -1, 2] == img[-1, -1, 2]   # clamped borders
+    half = LO.resize(np.full((8, 8, 3), 200, np.uint8), (4, 4))
+    assert (half == 200).all()                                              # constants stay constant through the fixed point
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(CASES)))
+def test_hip_letterbox_matches_reference_golden(dev, i):
+    """Bit-exact (8-bit integers) against the reference's letterbox output; both destination layouts."""
+    from msod_amd.utils.datasets import letterbox
+    c = CASES[i]
+    img = c["img"].to(dev)
+    out, ratio, pad = letterbox(img, **dict(c["kwargs"]))
+    torch.cuda.synchronize()
+    assert out.shape == c["out"].shape and torch.equal(out.cpu(), c["out"])
+    assert tuple(float(r) for r in ratio) == c["ratio"] and tuple(float(p) for p in pad) == c["pad"]
+    chw, _, _ = letterbox(img, chw_rgb=True, **dict(c["kwargs"]))
+    want = torch.from_numpy(np.ascontiguousarray(c["out"].numpy()[:, :, ::-1].transpose(2, 0, 1)))   # datasets.py:1276-1281
+    assert torch.equal(chw.cpu(), want)
+
+
+@pytest.mark.gpu
+def test_letterboxed_uint8_pair_feeds_the_model(dev):
+    """The whole caller-side chain on the device: two camera images -> letterbox (RGB + IR into one [6,H,W] uint8 block)
+    -> model on the uint8 views; against the oracle on the reference's own pre-processing of the same images
+    (letterbox -> BGR2RGB / CHW -> /255, utils/datasets.py:1206-1281, test.py:106-113)."""
+    from msod_amd.models.configs import named_config
+    from msod_amd.models.yolo_test import Model
+    from msod_amd.utils.datasets import letterbox_pair
+    from msod_amd.utils.seeded import seeded_state_dict
+    from oracle.cft_oracle import OracleModel
+    rng = np.random.RandomState(3)
+    bgr_rgb = rng.randint(0, 256, (150, 200, 3)).astype(np.uint8)
+    bgr_ir = rng.randint(0, 256, (150, 200, 3)).astype(np.uint8)
+    block, ratio, pad = letterbox_pair(torch.from_numpy(bgr_rgb).to(dev), torch.from_numpy(bgr_ir).to(dev), new_shape=128, stride=32)
+    ref = []
+    for im in (bgr_rgb, bgr_ir):
+        lb, _, _ = _oracle_letterbox(im, new_shape=128, auto=False, scaleup=False, stride=32)
+        ref.append(np.ascontiguousarray(lb[:, :, ::-1].transpose(2, 0, 1)))
+    want6 = torch.from_numpy(np.concatenate(ref, 0))
+    assert torch.equal(block.cpu(), want6)
+    cfg = named_config("cfg2")
+    model = Model(cfg)
+    sd = seeded_state_dict(model.state_dict(), 4)
+    model.load_state_dict(sd)
+    f = want6.float()[None] / 255.0
+    want_pred, want_raw = OracleModel(cfg)(sd, f[:, :3], f[:, 3:])
+    model = model.to(dev).set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        pred, raw = model(block[None, :3], block[None, 3:])
+    for a, b in zip(raw, want_raw):
+        assert (a.cpu() - b).abs().max().item() <= 1e-3
+    assert torch.allclose(pred.cpu(), want_pred, rtol=1e-3, atol=1e-3)
