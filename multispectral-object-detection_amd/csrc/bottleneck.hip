@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
   constexpr int PLANE = NRT * 16 * 128;                             // one 64-channel plane of the t patch (43008 B)
   constexpr int RING = 16384;                                       // one K tile of weights: 128 rows x 128 B
   constexpr int NBUF = 4;                                           // ring depth: three K tiles ahead of the compute tile
-  constexpr int NKT = 2 + 18;                                       // per pixel tile: W1 (2) + W2 (9 taps x 2 channel halves)
+  constexpr int NKT = 4 + 18;                                       // per pixel tile: W1 (2 K halves, streamed twice) + W2 (9 taps x 2 channel halves)
   constexpr int SLD = 64 + 4;
   constexpr int XTRA = 12;                                          // prefetch requests issued at the head of the 3x3 loop
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -287,14 +287,12 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
   const int wmr = wave >> 1, wnc = wave & 1;   // 3x3 loop: tile rows 4 wmr .. +4, channels 64 wnc .. +64
   const int tiles = p.tiles_x * p.tiles_y;
   if (tid < C) sB1[tid] = p.b1 != nullptr ? p.b1[tid] : 0.0f;     // (a global load inside the tile loop would drain the DMA ring)
-  float b2v[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) b2v[j] = p.b2 != nullptr ? p.b2[wnc * 64 + j * 16 + lrow] : 0.0f;
+  else if (tid < 2 * C) sB1[tid] = p.b2 != nullptr ? p.b2[tid - C] : 0.0f;    // sB1[128..255] = bias of the 3x3 conv
   const int my_tiles = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // this workgroup walks tiles bid, bid + grid, ...
   const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(cft_zero_page_b);
 
   // ---- weight ring: K tile = rows n (128) x 64 k; this thread stages rows r0 and r0 + 64, k-granule g.  The stream of
-  // K tiles is W1.k0 W1.k1 W2.(tap,half) x 18, repeated for every pixel tile of this workgroup (zero page afterwards).
+  // K tiles is W1.k0 W1.k1 W1.k0 W1.k1 W2.(tap,half) x 18, repeated for every pixel tile of this workgroup (zero page afterwards).
   const int r0 = tid >> 3, slot_s = tid & 7, g = slot_s ^ (r0 & 7);
   int st_kt = 0, st_left = my_tiles, sb = 0;
 #define BN128_STAGE(part_)                                                                               \
@@ -302,8 +300,8 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
     const int n_ = r0 + 64 * (part_);                                                                    \
     const unsigned char* src_;                                                                           \
     if (st_left <= 0) src_ = zero_page;                                                                  \
-    else if (st_kt < 2) src_ = p.w1 + ((long)n_ * p.kpad1 + st_kt * 64 + g * 8) * 2;                     \
-    else src_ = p.w2 + ((long)n_ * p.kpad2 + (st_kt - 2) * 64 + g * 8) * 2;                              \
+    else if (st_kt < 4) src_ = p.w1 + ((long)n_ * p.kpad1 + (st_kt & 1) * 64 + g * 8) * 2;               \
+    else src_ = p.w2 + ((long)n_ * p.kpad2 + (st_kt - 4) * 64 + g * 8) * 2;                              \
     if constexpr (!(ABL & 8))                                                                            \
       __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(sR + sb * RING + (part_) * 8192 + wave * 1024), 16, 0, 0); \
     if ((part_) == 1) {                                                                                  \
@@ -318,19 +316,17 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
   // after it, so that no global-load destination is live across the DMA ring's counted waits (hipcc drains vmcnt to 0
   // at the first use of a pending load result: that first use is the single hand-over point below).
   gran_t a1[3][4], a1n[3][4];
-  uint32_t inside = 0, inside_n = 0;   // bit it: this lane's patch pixel of row tile it lies in the image
+  static_assert(PW == 18, "the mul-shift below divides by 18");
 #define BN128_FETCH_X(tile_)                                                                             \
   {                                                                                                      \
     const int b_ = (tile_) / tiles, tt_ = (tile_) - b_ * tiles;                                          \
     const int ty_ = tt_ / p.tiles_x, tx_ = tt_ - ty_ * p.tiles_x;                                        \
     const long ip_ = (long)b_ * p.H * p.W;                                                               \
-    inside_n = 0;                                                                                        \
     _Pragma("unroll") for (int it = 0; it < 3; ++it) {                                                   \
       const int q = (wave + it * 8) * 16 + lrow;                                                         \
-      const int py = q / PW, px = q - py * PW;                                                           \
+      const int py = (q * 3641) >> 16, px = q - py * PW;      /* q / 18, exact for q < 32768 */          \
       const int zy = ty_ * TS - 1 + py, zx = tx_ * TS - 1 + px;                                          \
       const bool in_ = (tile_) >= 0 && q < NPIX && (unsigned)zy < (unsigned)p.H && (unsigned)zx < (unsigned)p.W; \
-      inside_n |= (in_ ? 1u : 0u) << it;                                                                 \
       /* always exactly 12 loads per wave (the counted waits of the 3x3 loop rely on it): outside pixels read the zero page */ \
       const unsigned char* px_ = in_ ? p.x + ((ip_ + (long)zy * p.W + zx) * p.ldx + p.xoff + lgrp * 8) * 2 : zero_page; \
       _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                   \
@@ -344,7 +340,6 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
         asm volatile("" : "+v"(a1n[it][ks]));   /* a real use: the load has landed from here on */       \
         a1[it][ks] = a1n[it][ks];                                                                        \
       }                                                                                                  \
-    inside = inside_n;                                                                                   \
   }
   BN128_FETCH_X((int)blockIdx.x)
   BN128_STAGE(0) BN128_STAGE(1)
@@ -367,7 +362,6 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
     const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
     const long img_pix = (long)b * p.H * p.W;
-    const uint32_t inside_cur = inside;
 #define BN128_STAMP(k_)                                                                                  \
     if constexpr (ABL & 32) {                                                                            \
       if (p.dbg != nullptr && lane == 0 && (wave & 3) == 0 && ti < 8)                                    \
@@ -376,26 +370,28 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
     BN128_STAMP(0)
     if (grp == 1) BN128_BARRIER()              // group 1 runs one barrier behind group 0
 
-    // ---- t^T = W1 x^T on the patch: two K tiles, two phases each (output channels 0-63 / 64-127)
-    f32x4_t acc1[3][8];
+    // ---- t^T = W1 x^T on the patch, output channels 0-63 then 64-127 (two passes over the two K halves of W1: half
+    // the accumulators and fragments of one pass over all 128 - the register budget of the kernel is set here);
+    // one load segment + one MFMA segment (24 MFMAs) per K tile; each pass ends with bias + SiLU -> 16-bit -> t patch
+    // (zero outside the image: the 3x3 conv's padding) while the other group is still in its MFMA segment
 #pragma unroll
-    for (int it = 0; it < 3; ++it)
+    for (int jh = 0; jh < 2; ++jh) {
+      f32x4_t acc1[3][4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc1[it][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int it = 0; it < 3; ++it)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      gran_t wf[8][2];      // all W1 fragments of this K tile are read in its FIRST phase (like the 3x3 loop's B fragments):
-                            // the ring buffer is re-staged three K tiles later, >= 2 phases after its last read by either group
+        for (int j = 0; j < 4; ++j) acc1[it][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ph = 0; ph < 2; ++ph) {
-        if (ph == 0) {
+      for (int kt = 0; kt < 2; ++kt) {
+        gran_t wf[4][2];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            wf[j][0] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + fb);
-            wf[j][1] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + (fb ^ 64));
-          }
+        for (int j = 0; j < 4; ++j) {
+          wf[j][0] = *reinterpret_cast<const gran_t*>(sR + cb * RING + (jh * 4 + j) * 2048 + fb);
+          wf[j][1] = *reinterpret_cast<const gran_t*>(sR + cb * RING + (jh * 4 + j) * 2048 + (fb ^ 64));
         }
-        BN128_STAGE(ph)                        // (K tiles 0-2 of this pixel tile landed before the loop / at the hand-over)
+        BN128_STAGE(0) BN128_STAGE(1)            // (K tiles 0-2 of this pixel tile landed before the loop / at the hand-over)
+        if (jh == 1) { asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }   // covers K tiles 3 (the second W1.k1) / 4 (the first W2 tile)
+        else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // fragment reads retired BEFORE the barrier: the other group may re-stage this buffer right after it
         BN128_BARRIER()
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -404,41 +400,40 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
           for (int it = 0; it < 3; ++it)
             if (wave + it * 8 < NRT) {   // wave-uniform
 #pragma unroll
-              for (int jj = 0; jj < 4; ++jj)
-                if constexpr (!(ABL & 1)) acc1[it][ph * 4 + jj] = mma_granule<T>(wf[ph * 4 + jj][ks], a1[it][kt * 2 + ks], acc1[it][ph * 4 + jj]);
+              for (int j = 0; j < 4; ++j)
+                if constexpr (!(ABL & 1)) acc1[it][j] = mma_granule<T>(wf[j][ks], a1[it][kt * 2 + ks], acc1[it][j]);
             }
         __builtin_amdgcn_s_setprio(0);
         BN128_BARRIER()
+        cb = cb == NBUF - 1 ? 0 : cb + 1;
       }
-      cb = cb == NBUF - 1 ? 0 : cb + 1;
-    }
-    BN128_STAMP(1)
-    if (grp == 0) BN128_BARRIER()                // both groups aligned again
-    // bias + SiLU -> 16-bit -> t patch (zero outside the image: the 3x3 conv's padding)
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
-      const int rt = wave + it * 8;
-      if (rt < NRT) {
-        const int q = rt * 16 + lrow;
-        const uint32_t keep = ((inside_cur >> it) & 1u) ? 0xffffffffu : 0u;
+      for (int it = 0; it < 3; ++it) {
+        const int rt = wave + it * 8;
+        if (rt < NRT) {
+          const int q = rt * 16 + lrow;
+          const int py = (q * 3641) >> 16, px = q - py * PW;
+          const uint32_t keep = (q < NPIX && (unsigned)(y0 - 1 + py) < (unsigned)p.H && (unsigned)(x0 - 1 + px) < (unsigned)p.W) ? 0xffffffffu : 0u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int c0 = j * 16 + lgrp * 4;        // first of this lane's 4 channels
-          float v[4];
-          const f32x4_t b1q = *reinterpret_cast<const f32x4_t*>(sB1 + c0);
+          for (int j = 0; j < 4; ++j) {
+            const int cc = j * 16 + lgrp * 4;        // first of this lane's 4 channels inside the 64-channel plane jh
+            float v[4];
+            const f32x4_t b1q = *reinterpret_cast<const f32x4_t*>(sB1 + jh * 64 + cc);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (ABL & 1) ? 0.0f : apply_act<CFT_ACT_SILU>(acc1[it][j][e] + b1q[e]);
-          uint2 w;
-          w.x = Elem<T>::pack2(v[0], v[1]) & keep;
-          w.y = Elem<T>::pack2(v[2], v[3]) & keep;
-          const int cc = c0 & 63;
-          // (inline asm: for a compiler-visible LDS store hipcc first drains vmcnt to 0 - the LDS-DMA ring could alias it)
-          const uint32_t ta = t_lds + (c0 >> 6) * PLANE + q * 128 + ((((cc >> 3) ^ (q & 7)) << 4) | ((cc & 7) << 1));
-          const unsigned long long wq = ((unsigned long long)w.y << 32) | w.x;
-          asm volatile("ds_write_b64 %0, %1" ::"v"(ta), "v"(wq) : "memory");
+            for (int e = 0; e < 4; ++e) v[e] = (ABL & 1) ? 0.0f : apply_act<CFT_ACT_SILU>(acc1[it][j][e] + b1q[e]);
+            uint2 w;
+            w.x = Elem<T>::pack2(v[0], v[1]) & keep;
+            w.y = Elem<T>::pack2(v[2], v[3]) & keep;
+            // (inline asm: for a compiler-visible LDS store hipcc first drains vmcnt to 0 - the LDS-DMA ring could alias it)
+            const uint32_t ta = t_lds + jh * PLANE + q * 128 + ((((cc >> 3) ^ (q & 7)) << 4) | ((cc & 7) << 1));
+            const unsigned long long wq = ((unsigned long long)w.y << 32) | w.x;
+            asm volatile("ds_write_b64 %0, %1" ::"v"(ta), "v"(wq) : "memory");
+          }
         }
       }
     }
+    BN128_STAMP(1)
+    if (grp == 0) BN128_BARRIER()                // both groups aligned again
     // requests that land under the 3x3 loop: the NEXT tile's x fragments (ALWAYS issued, 12 per wave - masked ones
     // read the zero page - because the counted vmcnt of the first two K tiles below allows for exactly that many)
     {
@@ -461,51 +456,44 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
       const int tap = kk >> 1, half = kk & 1;
       const int kh = tap / 3, kw = tap - kh * 3;
       const int qb = (wmr * 4 + kh) * PW + kw + lrow;      // patch pixel of tile row 4 wmr, this lane's column, this tap
-      gran_t af[2][2], bf[4][2];
-#define BN128_READ_A(i0_)                                                                                \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
-    const int q = qb + ((i0_) + i) * PW;                                                                 \
-    const unsigned char* rowp = sT + half * PLANE + q * 128;                                             \
-    af[i][0] = *reinterpret_cast<const gran_t*>(rowp + ((lgrp ^ (q & 7)) << 4));                         \
-    af[i][1] = *reinterpret_cast<const gran_t*>(rowp + (((4 + lgrp) ^ (q & 7)) << 4));                   \
-  }
-#define BN128_MMA(i0_)                                                                                   \
-  {                                                                                                      \
-    __builtin_amdgcn_s_setprio(1);                                                                       \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
-          if constexpr (ABL & 2) { asm volatile("" ::"v"(af[i][ks]), "v"(bf[j][ks])); }                  \
-          else acc[(i0_) + i][j] = mma_granule<T>(af[i][ks], bf[j][ks], acc[(i0_) + i][j]);              \
-        }                                                                                                \
-    __builtin_amdgcn_s_setprio(0);                                                                       \
-  }
-      // phase 1
-      BN128_READ_A(0)
+      gran_t af[4][2], bf[4][2];
+      // one load segment (8 A + 8 B fragment reads, the two staging requests of K tile kk + 3, the counted wait for
+      // K tile kk + 1) and one MFMA segment (32 MFMAs) per K tile: an inter-barrier interval is as long as its LONGER
+      // segment, and a 12-read load segment takes ~450 cycles against 272 for 16 MFMAs (tools/bneck_probe.py)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = qb + i * PW;
+        const unsigned char* rowp = sT + half * PLANE + q * 128;
+        af[i][0] = *reinterpret_cast<const gran_t*>(rowp + ((lgrp ^ (q & 7)) << 4));
+        af[i][1] = *reinterpret_cast<const gran_t*>(rowp + (((4 + lgrp) ^ (q & 7)) << 4));
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         bf[j][0] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + fbn);
         bf[j][1] = *reinterpret_cast<const gran_t*>(sR + cb * RING + j * 2048 + (fbn ^ 64));
       }
-      BN128_STAGE(0)
+      BN128_STAGE(0) BN128_STAGE(1)
+      // the wait covers the next K tile.  During the first two K tiles the prefetch requests issued just before the loop
+      // (x fragments of the next pixel tile) may still be in flight behind it.
+      if (kk < 2) { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + XTRA) : "memory"); }
+      else { asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
       BN128_BARRIER()
-      BN128_MMA(0)
-      BN128_BARRIER()
-      // phase 2; the wait covers the next K tile.  During the first two K tiles the prefetch requests issued just before
-      // the loop (x fragments of the next pixel tile, shortcut vectors) may still be in flight behind it.
-      BN128_READ_A(2)
-      BN128_STAGE(1)
-      if (kk < 2) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XTRA) : "memory"); }
-      else { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-      BN128_BARRIER()
-      BN128_MMA(2)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if constexpr (ABL & 2) { asm volatile("" ::"v"(af[i][ks]), "v"(bf[j][ks])); }
+            else acc[i][j] = mma_granule<T>(af[i][ks], bf[j][ks], acc[i][j]);
+          }
+      __builtin_amdgcn_s_setprio(0);
       BN128_BARRIER()
       cb = cb == NBUF - 1 ? 0 : cb + 1;
       if (kk == 2) BN128_STAMP(3)
     }
     BN128_STAMP(4)
-#undef BN128_READ_A
-#undef BN128_MMA
     // hand-over point: this tile's shortcut vectors are requested (L2 hits: the patch was read a few microseconds ago;
     // holding them in registers through the 3x3 loop would spill) and the next tile's x fragments are consumed, hipcc
     // waits vmcnt(0) for both - which also lands the first three K tiles of the next pixel tile
@@ -537,6 +525,9 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
 #pragma unroll
       for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(rs[i][0]), "v"(rs[i][1]));
     } else {
+      float b2v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b2v[j] = sB1[C + wnc * 64 + j * 16 + lrow];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -612,7 +603,7 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
     CFT_REQUIRE((long)B * q.tiles_x * q.tiles_y < (1L << 31), "cft_bottleneck: too many tiles");
     q.ntiles = B * q.tiles_x * q.tiles_y;
     q.dbg = g_bneck_dbg;
-    constexpr int smem128 = 2 * 21 * 16 * 128 + 4 * 16384 + 512;
+    constexpr int smem128 = 2 * 21 * 16 * 128 + 4 * 16384 + 1024;
     int cus = 256;
     {   // persistent: one workgroup per CU (148 KiB LDS each) walks tiles bid, bid + grid, ...
       static int cached = 0;
