@@ -63,17 +63,11 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // reads the staging buffers that the strips alias.
 template <typename TH, int WM, int WN, int ACT, bool OUT_F32>   // TH: the 16-bit storage type (bf16 bits or half)
 __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4_t (&acc)[WM / 16][WN / 16], unsigned char* smem,
-                                                   int m0, int n0, int wm, int wn, int wave, int lane) {
+                                                   int m0, int n0, int wm, int wn, int wave, int lane, const float (&bias_v)[WN / 16]) {
   constexpr int MT = WM / 16, NT = WN / 16;
   const int lrow = lane & 15, lgrp = lane >> 4;
   constexpr int SLD = WN + 4;  // fp32 strip leading dimension (+4: the four 4-row lane groups hit different banks)
   float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SLD);
-  float bias_v[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + wn * WN + j * 16 + lrow;
-    bias_v[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.0f;
-  }
   // bf16 residual (Bottleneck shortcut): every strip's residual vectors are requested up front, so their HBM
   // latency runs under the activation / LDS work instead of once per strip.  (The lane that reads an element is
   // the lane that later stores it, so an in-place residual stays correct.)
@@ -170,18 +164,30 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4_t 
 
 #undef CFT_RES_FETCH
 
+// This lane's bias values (output column j*16 + lrow of the wave tile).  Loaded BEFORE the K loop: at the epilogue the value
+// is a register, not an exposed L2 round trip per workgroup (and an ordinary load result consumed next to LDS-DMA traffic
+// makes hipcc drain vmcnt to 0 at that point).
+template <int WN>
+__device__ __forceinline__ void conv_load_bias(const ConvParams& p, int n0, int wn, int lane, float (&bias_v)[WN / 16]) {
+#pragma unroll
+  for (int j = 0; j < WN / 16; ++j) {
+    const int n = n0 + wn * WN + j * 16 + (lane & 15);
+    bias_v[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.0f;
+  }
+}
+
 // Uniform dispatch to the specialised epilogues (one activation / output type per launch).
 template <typename TH, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc)[WM / 16][WN / 16], unsigned char* smem,
-                                              int m0, int n0, int wm, int wn, int wave, int lane) {
+                                              int m0, int n0, int wm, int wn, int wave, int lane, const float (&bias_v)[WN / 16]) {
   if (p.out_f32) {
-    if (p.act == CFT_ACT_SILU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_SILU, true>(p, acc, smem, m0, n0, wm, wn, wave, lane);
-    else if (p.act == CFT_ACT_GELU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_GELU, true>(p, acc, smem, m0, n0, wm, wn, wave, lane);
-    else conv_epilogue_impl<TH, WM, WN, CFT_ACT_NONE, true>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+    if (p.act == CFT_ACT_SILU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_SILU, true>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
+    else if (p.act == CFT_ACT_GELU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_GELU, true>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
+    else conv_epilogue_impl<TH, WM, WN, CFT_ACT_NONE, true>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
   } else {
-    if (p.act == CFT_ACT_SILU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_SILU, false>(p, acc, smem, m0, n0, wm, wn, wave, lane);
-    else if (p.act == CFT_ACT_GELU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_GELU, false>(p, acc, smem, m0, n0, wm, wn, wave, lane);
-    else conv_epilogue_impl<TH, WM, WN, CFT_ACT_NONE, false>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+    if (p.act == CFT_ACT_SILU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_SILU, false>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
+    else if (p.act == CFT_ACT_GELU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_GELU, false>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
+    else conv_epilogue_impl<TH, WM, WN, CFT_ACT_NONE, false>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
   }
 }
 
@@ -310,6 +316,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bias_v[NT];
+  if constexpr (!(ABLATE & 32)) conv_load_bias<WN>(p, n0, wn, lane, bias_v);
 
   const int nk = p.Kpad / BK;
   CFT_LOAD_TILE(0, 0)
@@ -354,7 +362,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
       for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  conv_epilogue<typename Half16<T>::type, WM, WN>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+  if constexpr (ABLATE & 32) conv_load_bias<WN>(p, n0, wn, lane, bias_v);   // A/B probe: the round-1 placement
+  conv_epilogue<typename Half16<T>::type, WM, WN>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
 }
 
 // ------------------------------------------------------------------------------------ 8-phase kernel
@@ -571,7 +580,9 @@ __global__ void __launch_bounds__(512) conv_gemm8_kernel(const ConvParams p) {
       for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  conv_epilogue<T, 128, 64>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+  float bias_v[4];
+  conv_load_bias<64>(p, n0, wn, lane, bias_v);
+  conv_epilogue<T, 128, 64>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
 }
 
 // 256 x 128 x 64 sibling for the 128-channel layers (N <= 128): eight waves as 2 M-groups x 4, wave tile 128 x 32, the same
@@ -748,7 +759,9 @@ __global__ void __launch_bounds__(512) conv_gemm8n_kernel(const ConvParams p) {
       for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  conv_epilogue<T, 128, 32>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+  float bias_v[2];
+  conv_load_bias<32>(p, n0, wn, lane, bias_v);
+  conv_epilogue<T, 128, 32>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
 }
 
 // ------------------------------------------------------------------------------------ host
@@ -853,6 +866,9 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
     case 73: return launch_conv<T, 256, 80, 4, 1, true>(p, stream);
     case 74: return launch_conv<T, 256, 80, 8, 1, true>(p, stream);
     case 75: return launch_conv<T, 128, 80, 4, 1, true>(p, stream);
+    case 3223: return launch_conv<T, 128, 128, 2, 4, true, 32>(p, stream);   // 32xx: bias loaded at the epilogue (round-1 placement)
+    case 3251: return launch_conv<T, 192, 128, 2, 4, true, 32>(p, stream);
+    case 3227: return launch_conv<T, 256, 256, 4, 4, true, 32>(p, stream);
     case 1627: return launch_conv<T, 256, 256, 4, 4, true, 16>(p, stream);
     case 127: return launch_conv<T, 256, 256, 4, 4, true, 1>(p, stream);
     case 227: return launch_conv<T, 256, 256, 4, 4, true, 2>(p, stream);

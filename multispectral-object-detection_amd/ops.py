@@ -204,14 +204,24 @@ def conv2d(x, pk, act, residual=None, out=None, out_dtype=None):
     return out
 
 
-FUSED_BOTTLENECK_WIDTHS = (64, 128)   # cft_bottleneck: 64 (3x3 weights LDS-resident), 128 (activation patch resident, weights streamed)
+# cft_bottleneck covers 64 channels (3x3 weights LDS-resident) and 128 channels (activation patch resident, weights
+# streamed; persistent).  The 128-channel kernel is bit-identical and tested but measured no faster than the two launches
+# it replaces inside the two-stream forward (profiles/r02_bottleneck128.md), so the modules only use it when
+# CFT_FUSE128=1 is set in the environment.
+import os as _os
+FUSED_BOTTLENECK_WIDTHS = (64, 128) if _os.environ.get("CFT_FUSE128", "0") == "1" else (64,)
 
 
 def bottleneck_fusable(x, pk1, pk2, act1, act2):
     """True when ``bottleneck`` below can run as the single cft_bottleneck kernel."""
+    return bottleneck_kernel_covers(x, pk1, pk2, act1, act2) and x.shape[1] in FUSED_BOTTLENECK_WIDTHS
+
+
+def bottleneck_kernel_covers(x, pk1, pk2, act1, act2):
+    """True when cft_bottleneck implements this Bottleneck at all (64 or 128 channels, 16-bit, SiLU)."""
     return (x.dtype in (torch.bfloat16, torch.float16) and act1 == ACT_SILU and act2 == ACT_SILU
             and pk1.k == 1 and pk1.s == 1 and pk2.k == 3 and pk2.s == 1
-            and pk1.cin == pk1.n == pk2.cin == pk2.n == x.shape[1] and x.shape[1] in FUSED_BOTTLENECK_WIDTHS)
+            and pk1.cin == pk1.n == pk2.cin == pk2.n == x.shape[1] and x.shape[1] in (64, 128))
 
 
 def bottleneck(x, pk1, pk2, shortcut, out=None):

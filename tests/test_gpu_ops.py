@@ -365,7 +365,7 @@ def test_bottleneck_fused_is_bit_identical(dev, shortcut, hw, dtype, C):
     wide[:, :C] = x
     d = to_dev_nhwc(wide, dev, dtype)            # x = first half of a 2C-channel buffer (as inside C3)
     xin = d[:, :C]
-    assert ops.bottleneck_fusable(xin, pk1, pk2, 1, 1)
+    assert ops.bottleneck_kernel_covers(xin, pk1, pk2, 1, 1)
     two = ops.conv2d(ops.conv2d(xin, pk1, 1), pk2, 1, residual=xin if shortcut else None)
     fused = ops.bottleneck(xin, pk1, pk2, shortcut)
     ops.bottleneck(xin, pk1, pk2, shortcut, out=d[:, C:])      # disjoint slice of the same buffer
