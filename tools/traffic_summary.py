@@ -1,4 +1,4 @@
-"""Reduce the PMC passes of tools/pmc_traffic.sh to profiles/r01_traffic.json (bytes per forward per kernel)."""
+"""Reduce the PMC passes of tools/pmc_traffic.sh to profiles/r02_traffic.json (bytes per forward per kernel)."""
 import csv
 import glob
 import json
