@@ -14,6 +14,7 @@
 // The image loads of tile i+1 (phase-1 operands) and the shortcut vectors are requested before phase 2 of tile i.
 // Products, 32-wide k chunks, their order and every rounding are those of the two-launch path: bit-identical.
 #include "cft_common.h"
+#include <stdlib.h>
 
 extern int g_conv_variant;   // conv_gemm.hip (cft_set_conv_variant)
 
@@ -574,6 +575,235 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
 #undef BN128_HANDOVER
 }
 
+// ------------------------------------------------------------------------------------ 128 channels, two workgroups per CU
+// The same fused Bottleneck with the OTHER answer to its latency exposure (profiles/r02_bottleneck128.md): instead of one
+// persistent workgroup per CU that prefetches across tiles, TWO co-resident workgroups per CU (80 KiB LDS each, 8 x 16-pixel
+// tiles: 48 KiB t patch + two 16-KiB ring buffers), plain lock-step K loop (stage K tile c + 1, compute K tile c, barrier):
+// one workgroup's x loads / t write / epilogue / DMA waits run under the other's MFMAs - the mechanism that makes the
+// 192 x 128 tile the best 128-wide GEMM tile.  Wave (wmr, wnc) owns tile rows 2 wmr, 2 wmr + 1 x 64 channels.
+// Biases live in the 12 spare rows of plane 1 of the t patch (patch pixels 180..191 do not exist).
+template <typename T, int ABL = 0>
+__global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Params p) {
+  constexpr int C = 128, TH = 8, TW = 16, PW = TW + 2, PH = TH + 2, NPIX = PW * PH;   // 180 patch pixels
+  constexpr int NRT = (NPIX + 15) / 16;                             // 12 row tiles of the patch
+  constexpr int PLANE = NRT * 16 * 128;                             // 24576 B
+  constexpr int RING = 16384;
+  constexpr int NKT = 4 + 18;
+  constexpr int SLD = 64 + 4;
+  static_assert(PW == 18, "the mul-shift below divides by 18");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sT = smem;
+  unsigned char* sR = smem + 2 * PLANE;
+  float* sB = reinterpret_cast<float*>(smem + PLANE + NPIX * 128);   // [256]: b1 then b2, in the spare rows of plane 1
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  const int wmr = wave >> 1, wnc = wave & 1;
+  const int tiles = p.tiles_x * p.tiles_y;
+  const int b = blockIdx.x / tiles, tt = blockIdx.x - b * tiles;
+  const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const long img_pix = (long)b * p.H * p.W;
+  const uint32_t t_lds = (uint32_t)(uintptr_t)(lds_void_t*)sT;
+
+  // x fragments: row tile rt = wave + 8 it (it = 1 only for waves 0-3)
+  gran_t a1[2][4];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int q = (wave + it * 8) * 16 + lrow;
+    const int py = (q * 3641) >> 16, px = q - py * PW;
+    const int zy = y0 - 1 + py, zx = x0 - 1 + px;
+    const bool in_ = q < NPIX && (unsigned)zy < (unsigned)p.H && (unsigned)zx < (unsigned)p.W;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      gran_t t = {0u, 0u, 0u, 0u};
+      if (in_) t = *reinterpret_cast<const gran_t*>(p.x + ((img_pix + (long)zy * p.W + zx) * p.ldx + p.xoff + ks * 32 + lgrp * 8) * 2);
+      a1[it][ks] = t;
+    }
+  }
+  if (tid < C) sB[tid] = p.b1 != nullptr ? p.b1[tid] : 0.0f;
+  else if (tid < 2 * C) sB[tid] = p.b2 != nullptr ? p.b2[tid - C] : 0.0f;
+
+  const int r0 = tid >> 3, slot_s = tid & 7, g = slot_s ^ (r0 & 7);
+#define BNB_STAGE(kt_)                                                                                   \
+  _Pragma("unroll") for (int part_ = 0; part_ < 2; ++part_) {                                            \
+    const int n_ = r0 + 64 * part_;                                                                      \
+    const unsigned char* src_ = (kt_) < 4 ? p.w1 + ((long)n_ * p.kpad1 + ((kt_) & 1) * 64 + g * 8) * 2   \
+                                          : p.w2 + ((long)n_ * p.kpad2 + ((kt_) - 4) * 64 + g * 8) * 2;  \
+    if constexpr (!(ABL & 8))                                                                            \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(sR + ((kt_) & 1) * RING + part_ * 8192 + wave * 1024), 16, 0, 0); \
+  }
+  BNB_STAGE(0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const int fb = lrow * 128 + ((lgrp ^ (lrow & 7)) << 4);
+  const int fbn = (wnc * 64 + lrow) * 128 + ((lgrp ^ (lrow & 7)) << 4);
+
+  // ---- t^T = W1 x^T: output channels 0-63 / 64-127 (K tiles 0,1 / 2,3), then bias + SiLU -> t patch
+#pragma unroll
+  for (int jh = 0; jh < 2; ++jh) {
+    f32x4_t acc1[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc1[it][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int c = jh * 2 + kt;
+      BNB_STAGE(c + 1)
+      gran_t wf[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        wf[j][0] = *reinterpret_cast<const gran_t*>(sR + (c & 1) * RING + (jh * 4 + j) * 2048 + fb);
+        wf[j][1] = *reinterpret_cast<const gran_t*>(sR + (c & 1) * RING + (jh * 4 + j) * 2048 + (fb ^ 64));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+          if (wave + it * 8 < NRT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if constexpr (!(ABL & 1)) acc1[it][j] = mma_granule<T>(wf[j][ks], a1[it][kt * 2 + ks], acc1[it][j]);
+          }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // K tile c + 1 landed; this tile's fragment reads retired
+      __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int q = (wave + it * 8) * 16 + lrow;
+      if (wave + it * 8 < NRT && q < NPIX) {
+        const int py = (q * 3641) >> 16, px = q - py * PW;
+        const uint32_t keep = ((unsigned)(y0 - 1 + py) < (unsigned)p.H && (unsigned)(x0 - 1 + px) < (unsigned)p.W) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cc = j * 16 + lgrp * 4;
+          const f32x4_t b1q = *reinterpret_cast<const f32x4_t*>(sB + jh * 64 + cc);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (ABL & 1) ? 0.0f : apply_act<CFT_ACT_SILU>(acc1[it][j][e] + b1q[e]);
+          uint2 w;
+          w.x = Elem<T>::pack2(v[0], v[1]) & keep;
+          w.y = Elem<T>::pack2(v[2], v[3]) & keep;
+          const uint32_t ta = t_lds + jh * PLANE + q * 128 + ((((cc >> 3) ^ (q & 7)) << 4) | ((cc & 7) << 1));
+          const unsigned long long wq = ((unsigned long long)w.y << 32) | w.x;
+          asm volatile("ds_write_b64 %0, %1" ::"v"(ta), "v"(wq) : "memory");
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                       // the whole t patch is visible
+
+  // ---- 3x3 conv of the t patch
+  f32x4_t acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int kk = 0; kk < 18; ++kk) {
+    const int c = kk + 4;
+    if (kk + 1 < 18) BNB_STAGE(c + 1)
+    const int tap = kk >> 1, half = kk & 1;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int qb = (wmr * 2 + kh) * PW + kw + lrow;
+    gran_t af[2][2], bf[4][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = qb + i * PW;
+      const unsigned char* rowp = sT + half * PLANE + q * 128;
+      af[i][0] = *reinterpret_cast<const gran_t*>(rowp + ((lgrp ^ (q & 7)) << 4));
+      af[i][1] = *reinterpret_cast<const gran_t*>(rowp + (((4 + lgrp) ^ (q & 7)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf[j][0] = *reinterpret_cast<const gran_t*>(sR + (c & 1) * RING + j * 2048 + fbn);
+      bf[j][1] = *reinterpret_cast<const gran_t*>(sR + (c & 1) * RING + j * 2048 + (fbn ^ 64));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (ABL & 2) { asm volatile("" ::"v"(af[i][ks]), "v"(bf[j][ks])); }
+          else acc[i][j] = mma_granule<T>(af[i][ks], bf[j][ks], acc[i][j]);
+        }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#undef BNB_STAGE
+
+  // ---- epilogue: strip i = tile row 2 wmr + i, 16 pixels x 64 channels
+  if constexpr (ABL & 4) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+  float b2v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b2v[j] = sB[C + wnc * 64 + j * 16 + lrow];
+  gran_t rs[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int it = lane + v * 64;
+      const int row = it >> 3, col = (it & 7) * 8;
+      const int x = x0 + row, y = y0 + wmr * 2 + i;
+      gran_t t = {0u, 0u, 0u, 0u};
+      if (p.shortcut && x < p.W && y < p.H)
+        t = *reinterpret_cast<const gran_t*>(p.x + ((img_pix + (long)y * p.W + x) * p.ldx + p.xoff + wnc * 64 + col) * 2);
+      rs[i][v] = t;
+    }
+  __builtin_amdgcn_s_barrier();                       // (after b2v was read) the strips may overwrite the t patch; the bias rows lie beyond them
+  float* stage = reinterpret_cast<float*>(sT) + wave * (16 * SLD);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        stage[(lgrp * 4 + e) * SLD + j * 16 + lrow] = apply_act<CFT_ACT_SILU>(acc[i][j][e] + b2v[j]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int it = lane + v * 64;
+      const int row = it >> 3, col = (it & 7) * 8;
+      const int x = x0 + row, y = y0 + wmr * 2 + i;
+      if (x < p.W && y < p.H) {
+        const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col);
+        const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col + 4);
+        float o[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        if (p.shortcut) {
+          float rf[8];
+          Elem<T>::unpack(rs[i][v], rf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += rf[e];
+        }
+        *reinterpret_cast<gran_t*>(p.y + ((img_pix + (long)y * p.W + x) * p.ldy + p.yoff + wnc * 64 + col) * 2) = Elem<T>::pack(o);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// CFT_BNECK128=persistent selects the one-workgroup-per-CU kernel; the default is the two-per-CU kernel.
+static bool bneck128_two_per_cu() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CFT_BNECK128"); v = (e && e[0] == 'p') ? 0 : 1; }
+  return v == 1;
+}
+
 extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, int kpad1, const float* b1,
                               const void* w2, int kpad2, const float* b2, void* y, int ldy, int yoff,
                               int B, int H, int W, int c, int shortcut, int dtype, void* stream) {
@@ -593,6 +823,36 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
     const bool disjoint_mem = ya + ybytes <= xa || xa + xbytes <= ya;
     const bool disjoint_slice = ldx == ldy && d >= (long)c * 2 && d + (long)c * 2 <= (long)ldx * 2;   // same pixel grid, other channels
     CFT_REQUIRE(disjoint_mem || disjoint_slice, "cft_bottleneck: output overlaps the input (halo reads forbid in-place)");
+  }
+  if (c == 128 && bneck128_two_per_cu() && g_conv_variant != 9128 && g_conv_variant != 932) {   // variant 9128 / 932: the persistent kernel
+    Bneck128Params q;
+    q.x = (const unsigned char*)x; q.w1 = (const unsigned char*)w1; q.w2 = (const unsigned char*)w2;
+    q.b1 = b1; q.b2 = b2; q.y = (unsigned char*)y;
+    q.ldx = ldx; q.xoff = xoff; q.ldy = ldy; q.yoff = yoff; q.kpad1 = kpad1; q.kpad2 = kpad2;
+    q.H = H; q.W = W; q.tiles_x = (W + 15) / 16; q.tiles_y = (H + 7) / 8; q.shortcut = shortcut ? 1 : 0;
+    q.ntiles = B * q.tiles_x * q.tiles_y; q.dbg = nullptr;
+    CFT_REQUIRE((long)B * q.tiles_x * q.tiles_y < (1L << 31), "cft_bottleneck: too many tiles");
+    constexpr int smemb = 2 * 12 * 16 * 128 + 2 * 16384;
+    const dim3 gridb(q.ntiles), blockb(512);
+    hipStream_t sb_ = as_stream(stream);
+#define BNB_LAUNCH(T_, ABL_)                                                                      \
+    {                                                                                             \
+      cft_allow_lds<&bottleneck128b_kernel<T_, ABL_>>(smemb);                                     \
+      hipLaunchKernelGGL((bottleneck128b_kernel<T_, ABL_>), gridb, blockb, smemb, sb_, q);        \
+    }
+    if (dtype == CFT_F16) {
+      BNB_LAUNCH(f16_t, 0)
+    } else {
+      switch (g_conv_variant) {
+        case 901: BNB_LAUNCH(uint16_t, 1) break;
+        case 902: BNB_LAUNCH(uint16_t, 2) break;
+        case 904: BNB_LAUNCH(uint16_t, 4) break;
+        case 908: BNB_LAUNCH(uint16_t, 8) break;
+        default: BNB_LAUNCH(uint16_t, 0) break;
+      }
+    }
+#undef BNB_LAUNCH
+    return cft_check_launch("bottleneck128b_kernel");
   }
   if (c == 128) {
     Bneck128Params q;

@@ -375,8 +375,17 @@ def test_bottleneck_fused_is_bit_identical(dev, shortcut, hw, dtype, C):
     assert torch.equal(d[:, :C].float().cpu(), x), "input slice untouched"
     with pytest.raises(RuntimeError):
         ops.bottleneck(xin, pk1, pk2, shortcut, out=xin)         # in-place is refused (halo reads)
+    if C == 128:      # the persistent one-workgroup-per-CU implementation of the same kernel (variant 9128)
+        from msod_amd import _lib
+        _lib.load().cft_set_conv_variant(9128)
+        try:
+            pers = ops.bottleneck(xin, pk1, pk2, shortcut)
+            torch.cuda.synchronize()
+        finally:
+            _lib.load().cft_set_conv_variant(0)
+        assert torch.equal(pers.float().cpu(), two.float().cpu())
     ref = O.bottleneck(sd, "m.", x, shortcut)
-    assert rel_err(to_cpu_f32(fused), ref) < 2 * tol(dtype)   # two bf16 roundings (hidden tensor, output)
+    assert rel_err(to_cpu_f32(fused), ref) < 2 * tol(dtype)   # two 16-bit roundings (hidden tensor, output)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
