@@ -723,6 +723,7 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
       bf[j][0] = *reinterpret_cast<const gran_t*>(sR + (c & 1) * RING + j * 2048 + fbn);
       bf[j][1] = *reinterpret_cast<const gran_t*>(sR + (c & 1) * RING + j * 2048 + (fbn ^ 64));
     }
+    if constexpr (ABL & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -732,6 +733,7 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
           if constexpr (ABL & 2) { asm volatile("" ::"v"(af[i][ks]), "v"(bf[j][ks])); }
           else acc[i][j] = mma_granule<T>(af[i][ks], bf[j][ks], acc[i][j]);
         }
+    if constexpr (ABL & 16) __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
@@ -848,6 +850,7 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
         case 902: BNB_LAUNCH(uint16_t, 2) break;
         case 904: BNB_LAUNCH(uint16_t, 4) break;
         case 908: BNB_LAUNCH(uint16_t, 8) break;
+        case 916: BNB_LAUNCH(uint16_t, 16) break;
         default: BNB_LAUNCH(uint16_t, 0) break;
       }
     }

@@ -204,12 +204,12 @@ def conv2d(x, pk, act, residual=None, out=None, out_dtype=None):
     return out
 
 
-# cft_bottleneck covers 64 channels (3x3 weights LDS-resident) and 128 channels (activation patch resident, weights
-# streamed; persistent).  The 128-channel kernel is bit-identical and tested but measured no faster than the two launches
-# it replaces inside the two-stream forward (profiles/r02_bottleneck128.md), so the modules only use it when
-# CFT_FUSE128=1 is set in the environment.
+# cft_bottleneck covers 64 channels (3x3 weights LDS-resident, one workgroup per CU) and 128 channels (activation patch
+# resident, weights streamed; two workgroups per CU: 187 vs 234 us for the two launches it replaces, +2.9 % pairs/s on
+# the forward - profiles/r02_bottleneck128.md).  CFT_FUSE128=0 in the environment restores the two-launch path for the
+# 128-channel stage (A/B runs); CFT_BNECK128=persistent selects the one-workgroup-per-CU implementation of the kernel.
 import os as _os
-FUSED_BOTTLENECK_WIDTHS = (64, 128) if _os.environ.get("CFT_FUSE128", "0") == "1" else (64,)
+FUSED_BOTTLENECK_WIDTHS = (64,) if _os.environ.get("CFT_FUSE128", "1") == "0" else (64, 128)
 
 
 def bottleneck_fusable(x, pk1, pk2, act1, act2):
