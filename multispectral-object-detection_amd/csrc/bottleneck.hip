@@ -582,14 +582,17 @@ __global__ void __launch_bounds__(512) bottleneck128_kernel(const Bneck128Params
 // one workgroup's x loads / t write / epilogue / DMA waits run under the other's MFMAs - the mechanism that makes the
 // 192 x 128 tile the best 128-wide GEMM tile.  Wave (wmr, wnc) owns tile rows 2 wmr, 2 wmr + 1 x 64 channels.
 // Biases live in the 12 spare rows of plane 1 of the t patch (patch pixels 180..191 do not exist).
-template <typename T, int ABL = 0>
-__global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Params p) {
+template <typename T, int NW, int ABL = 0>   // NW = waves per workgroup: 8 (wave tile 2 rows x 64 ch) or 4 (4 rows x 64 ch: 0.5 instead of
+                                             // 0.75 fragment reads per MFMA - with 16 waves per CU the 8-wave form is LDS-read bound)
+__global__ void __launch_bounds__(64 * NW, NW / 2) bottleneck128b_kernel(const Bneck128Params p) {
   constexpr int C = 128, TH = 8, TW = 16, PW = TW + 2, PH = TH + 2, NPIX = PW * PH;   // 180 patch pixels
   constexpr int NRT = (NPIX + 15) / 16;                             // 12 row tiles of the patch
   constexpr int PLANE = NRT * 16 * 128;                             // 24576 B
   constexpr int RING = 16384;
   constexpr int NKT = 4 + 18;
   constexpr int SLD = 64 + 4;
+  constexpr int NTHR = 64 * NW, RW = 16 / NW, RT1 = (NRT + NW - 1) / NW, SPT = 1024 / NTHR, SROWS = NTHR / 8;
+  static_assert(NW == 8 || NW == 4, "8 or 4 waves");
   static_assert(PW == 18, "the mul-shift below divides by 18");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sT = smem;
@@ -599,7 +602,7 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane & 15, lgrp = lane >> 4;
-  const int wmr = wave >> 1, wnc = wave & 1;
+  const int wmr = wave >> 1, wnc = wave & 1;      // 3x3 loop: tile rows RW wmr .. + RW, channels 64 wnc .. + 64
   const int tiles = p.tiles_x * p.tiles_y;
   const int b = blockIdx.x / tiles, tt = blockIdx.x - b * tiles;
   const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
@@ -607,11 +610,11 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
   const long img_pix = (long)b * p.H * p.W;
   const uint32_t t_lds = (uint32_t)(uintptr_t)(lds_void_t*)sT;
 
-  // x fragments: row tile rt = wave + 8 it (it = 1 only for waves 0-3)
-  gran_t a1[2][4];
+  // x fragments: row tile rt = wave + NW it
+  gran_t a1[RT1][4];
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int q = (wave + it * 8) * 16 + lrow;
+  for (int it = 0; it < RT1; ++it) {
+    const int q = (wave + it * NW) * 16 + lrow;
     const int py = (q * 3641) >> 16, px = q - py * PW;
     const int zy = y0 - 1 + py, zx = x0 - 1 + px;
     const bool in_ = q < NPIX && (unsigned)zy < (unsigned)p.H && (unsigned)zx < (unsigned)p.W;
@@ -627,12 +630,12 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
 
   const int r0 = tid >> 3, slot_s = tid & 7, g = slot_s ^ (r0 & 7);
 #define BNB_STAGE(kt_)                                                                                   \
-  _Pragma("unroll") for (int part_ = 0; part_ < 2; ++part_) {                                            \
-    const int n_ = r0 + 64 * part_;                                                                      \
+  _Pragma("unroll") for (int part_ = 0; part_ < SPT; ++part_) {                                          \
+    const int n_ = r0 + SROWS * part_;                                                                   \
     const unsigned char* src_ = (kt_) < 4 ? p.w1 + ((long)n_ * p.kpad1 + ((kt_) & 1) * 64 + g * 8) * 2   \
                                           : p.w2 + ((long)n_ * p.kpad2 + ((kt_) - 4) * 64 + g * 8) * 2;  \
     if constexpr (!(ABL & 8))                                                                            \
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(sR + ((kt_) & 1) * RING + part_ * 8192 + wave * 1024), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(sR + ((kt_) & 1) * RING + part_ * (SROWS * 128) + wave * 1024), 16, 0, 0); \
   }
   BNB_STAGE(0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -644,9 +647,9 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
   // ---- t^T = W1 x^T: output channels 0-63 / 64-127 (K tiles 0,1 / 2,3), then bias + SiLU -> t patch
 #pragma unroll
   for (int jh = 0; jh < 2; ++jh) {
-    f32x4_t acc1[2][4];
+    f32x4_t acc1[RT1][4];
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int it = 0; it < RT1; ++it)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc1[it][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -662,8 +665,8 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
-          if (wave + it * 8 < NRT) {
+        for (int it = 0; it < RT1; ++it)
+          if (wave + it * NW < NRT) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
               if constexpr (!(ABL & 1)) acc1[it][j] = mma_granule<T>(wf[j][ks], a1[it][kt * 2 + ks], acc1[it][j]);
@@ -672,9 +675,9 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
       __builtin_amdgcn_s_barrier();
     }
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int q = (wave + it * 8) * 16 + lrow;
-      if (wave + it * 8 < NRT && q < NPIX) {
+    for (int it = 0; it < RT1; ++it) {
+      const int q = (wave + it * NW) * 16 + lrow;
+      if (wave + it * NW < NRT && q < NPIX) {
         const int py = (q * 3641) >> 16, px = q - py * PW;
         const uint32_t keep = ((unsigned)(y0 - 1 + py) < (unsigned)p.H && (unsigned)(x0 - 1 + px) < (unsigned)p.W) ? 0xffffffffu : 0u;
 #pragma unroll
@@ -698,9 +701,9 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
   __builtin_amdgcn_s_barrier();                       // the whole t patch is visible
 
   // ---- 3x3 conv of the t patch
-  f32x4_t acc[2][4];
+  f32x4_t acc[RW][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RW; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -709,10 +712,10 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
     if (kk + 1 < 18) BNB_STAGE(c + 1)
     const int tap = kk >> 1, half = kk & 1;
     const int kh = tap / 3, kw = tap - kh * 3;
-    const int qb = (wmr * 2 + kh) * PW + kw + lrow;
-    gran_t af[2][2], bf[4][2];
+    const int qb = (wmr * RW + kh) * PW + kw + lrow;
+    gran_t af[RW][2], bf[4][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RW; ++i) {
       const int q = qb + i * PW;
       const unsigned char* rowp = sT + half * PLANE + q * 128;
       af[i][0] = *reinterpret_cast<const gran_t*>(rowp + ((lgrp ^ (q & 7)) << 4));
@@ -727,7 +730,7 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < RW; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if constexpr (ABL & 2) { asm volatile("" ::"v"(af[i][ks]), "v"(bf[j][ks])); }
@@ -739,10 +742,10 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
   }
 #undef BNB_STAGE
 
-  // ---- epilogue: strip i = tile row 2 wmr + i, 16 pixels x 64 channels
+  // ---- epilogue: strip i = tile row RW wmr + i, 16 pixels x 64 channels
   if constexpr (ABL & 4) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RW; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
@@ -750,14 +753,14 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
   float b2v[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) b2v[j] = sB[C + wnc * 64 + j * 16 + lrow];
-  gran_t rs[2][2];
+  gran_t rs[RW][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RW; ++i)
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
       const int it = lane + v * 64;
       const int row = it >> 3, col = (it & 7) * 8;
-      const int x = x0 + row, y = y0 + wmr * 2 + i;
+      const int x = x0 + row, y = y0 + wmr * RW + i;
       gran_t t = {0u, 0u, 0u, 0u};
       if (p.shortcut && x < p.W && y < p.H)
         t = *reinterpret_cast<const gran_t*>(p.x + ((img_pix + (long)y * p.W + x) * p.ldx + p.xoff + wnc * 64 + col) * 2);
@@ -766,7 +769,7 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
   __builtin_amdgcn_s_barrier();                       // (after b2v was read) the strips may overwrite the t patch; the bias rows lie beyond them
   float* stage = reinterpret_cast<float*>(sT) + wave * (16 * SLD);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < RW; ++i) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -779,7 +782,7 @@ __global__ void __launch_bounds__(512, 4) bottleneck128b_kernel(const Bneck128Pa
     for (int v = 0; v < 2; ++v) {
       const int it = lane + v * 64;
       const int row = it >> 3, col = (it & 7) * 8;
-      const int x = x0 + row, y = y0 + wmr * 2 + i;
+      const int x = x0 + row, y = y0 + wmr * RW + i;
       if (x < p.W && y < p.H) {
         const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col);
         const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col + 4);
@@ -835,23 +838,28 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
     q.ntiles = B * q.tiles_x * q.tiles_y; q.dbg = nullptr;
     CFT_REQUIRE((long)B * q.tiles_x * q.tiles_y < (1L << 31), "cft_bottleneck: too many tiles");
     constexpr int smemb = 2 * 12 * 16 * 128 + 2 * 16384;
-    const dim3 gridb(q.ntiles), blockb(512);
+    const dim3 gridb(q.ntiles);
     hipStream_t sb_ = as_stream(stream);
-#define BNB_LAUNCH(T_, ABL_)                                                                      \
-    {                                                                                             \
-      cft_allow_lds<&bottleneck128b_kernel<T_, ABL_>>(smemb);                                     \
-      hipLaunchKernelGGL((bottleneck128b_kernel<T_, ABL_>), gridb, blockb, smemb, sb_, q);        \
+#define BNB_LAUNCH(T_, NW_, ABL_)                                                                       \
+    {                                                                                                   \
+      cft_allow_lds<&bottleneck128b_kernel<T_, NW_, ABL_>>(smemb);                                      \
+      hipLaunchKernelGGL((bottleneck128b_kernel<T_, NW_, ABL_>), gridb, dim3(64 * NW_), smemb, sb_, q); \
     }
     if (dtype == CFT_F16) {
-      BNB_LAUNCH(f16_t, 0)
+      if (g_conv_variant == 9004) BNB_LAUNCH(f16_t, 4, 0) else BNB_LAUNCH(f16_t, 8, 0)
     } else {
       switch (g_conv_variant) {
-        case 901: BNB_LAUNCH(uint16_t, 1) break;
-        case 902: BNB_LAUNCH(uint16_t, 2) break;
-        case 904: BNB_LAUNCH(uint16_t, 4) break;
-        case 908: BNB_LAUNCH(uint16_t, 8) break;
-        case 916: BNB_LAUNCH(uint16_t, 16) break;
-        default: BNB_LAUNCH(uint16_t, 0) break;
+        case 901: BNB_LAUNCH(uint16_t, 8, 1) break;
+        case 902: BNB_LAUNCH(uint16_t, 8, 2) break;
+        case 904: BNB_LAUNCH(uint16_t, 8, 4) break;
+        case 908: BNB_LAUNCH(uint16_t, 8, 8) break;
+        case 916: BNB_LAUNCH(uint16_t, 8, 16) break;
+        case 9004: BNB_LAUNCH(uint16_t, 4, 0) break;        // four waves per workgroup, wave tile 4 rows x 64 channels
+        case 9014: BNB_LAUNCH(uint16_t, 4, 1) break;
+        case 9024: BNB_LAUNCH(uint16_t, 4, 2) break;
+        case 9044: BNB_LAUNCH(uint16_t, 4, 4) break;
+        case 9084: BNB_LAUNCH(uint16_t, 4, 8) break;
+        default: BNB_LAUNCH(uint16_t, 8, 0) break;
       }
     }
 #undef BNB_LAUNCH

@@ -375,15 +375,16 @@ def test_bottleneck_fused_is_bit_identical(dev, shortcut, hw, dtype, C):
     assert torch.equal(d[:, :C].float().cpu(), x), "input slice untouched"
     with pytest.raises(RuntimeError):
         ops.bottleneck(xin, pk1, pk2, shortcut, out=xin)         # in-place is refused (halo reads)
-    if C == 128:      # the persistent one-workgroup-per-CU implementation of the same kernel (variant 9128)
+    if C == 128:      # the other implementations of the same kernel: persistent one-workgroup-per-CU (9128), 4-wave workgroups (9004)
         from msod_amd import _lib
-        _lib.load().cft_set_conv_variant(9128)
-        try:
-            pers = ops.bottleneck(xin, pk1, pk2, shortcut)
-            torch.cuda.synchronize()
-        finally:
-            _lib.load().cft_set_conv_variant(0)
-        assert torch.equal(pers.float().cpu(), two.float().cpu())
+        for variant in (9128, 9004):
+            _lib.load().cft_set_conv_variant(variant)
+            try:
+                other = ops.bottleneck(xin, pk1, pk2, shortcut)
+                torch.cuda.synchronize()
+            finally:
+                _lib.load().cft_set_conv_variant(0)
+            assert torch.equal(other.float().cpu(), two.float().cpu()), variant
     ref = O.bottleneck(sd, "m.", x, shortcut)
     assert rel_err(to_cpu_f32(fused), ref) < 2 * tol(dtype)   # two 16-bit roundings (hidden tensor, output)
 
