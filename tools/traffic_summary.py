@@ -19,7 +19,7 @@ for c in tot:
             tot[c][k] += float(row["Counter_Value"]) * 1024.0        # counters are in KiB
             if c == "FETCH_SIZE":
                 calls[k] += 1
-GEMM_FAMILY = ("conv_gemm", "focus_conv", "bottleneck_kernel")   # the implicit-GEMM kernels bench.py times as one family
+GEMM_FAMILY = ("conv_gemm", "focus_conv", "bottleneck")   # the implicit-GEMM kernels bench.py times as one family
 focus = [k for k in calls if "focus_conv" in k or "focus_s2d" in k]
 n_fwd = calls[focus[0]] / 2 if focus else 1          # two Focus launches per forward
 kern = {}
