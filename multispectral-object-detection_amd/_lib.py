@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ("runtime.hip", "conv_gemm.hip", "focus_conv.hip", "bottleneck.hip", "pointwise.hip", "attention.hip", "nms.hip", "train.hip")
 
 CFT_BF16, CFT_F32, CFT_F16 = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 
 _c = ctypes
@@ -31,7 +31,8 @@ SIGNATURES = {
     "cft_conv2d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_set_conv_variant": [_i],
     "cft_set_debug_buffer": [_vp],
-    "cft_bottleneck": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_bottleneck": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_bottleneck_pack_w2": [_vp, _i, _i, _vp, _i, _vp],
     "cft_focus_s2d": [_vp, _vp, _i, _i, _i, _i, _vp],
     "cft_focus_s2d_u8": [_vp, _l, _l, _l, _vp, _i, _i, _i, _f, _i, _vp],
     "cft_focus_conv": [_vp, _i, _l, _l, _l, _f, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

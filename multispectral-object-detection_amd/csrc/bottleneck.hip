@@ -258,6 +258,7 @@ struct Bneck128Params {
   const unsigned char* x;
   const unsigned char* w1;   // [128][kpad1]
   const unsigned char* w2;   // [128][kpad2], k = (kh*3 + kw)*128 + ci
+  const unsigned char* w2s;  // the same weights as 36 stage images of 8 KiB (cft_bottleneck_pack_w2), or null
   const float* b1;
   const float* b2;
   unsigned char* y;
@@ -802,15 +803,336 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) bottleneck128b_kernel(const B
   }
 }
 
+// ------------------------------------------------------------------------------------ 128 channels, two per CU, 4-slot ring
+// bottleneck128b_kernel is bound by the latency of its weight stream: one 16-KiB K tile of lookahead (issued at the head of
+// a K tile, needed at its tail) against 0.21 us of MFMA work per K tile.  Same tile, same LDS budget (48 KiB t patch +
+// 32 KiB ring), same products in the same order, but
+//   * the ring is FOUR slots of 8 KiB: a stage is 32 k wide (W2: 128 rows x 64 B, slot = k-granule ^ h(row / 4)) and is
+//     issued three stages ahead with counted s_waitcnt vmcnt(2); W1 streams once (four stages of 64 rows x 128 B, one per
+//     output-channel half and k half);
+//   * the 3x3 loop is software-pipelined by hand: step s READS the fragments of stage s and runs the MFMAs of step s - 1
+//     under those reads;
+//   * the shortcut pixels are requested right after the LAST stage: vmcnt is in-order, so an earlier request would be
+//     waited for together with the next stage, three steps later;
+//   * the patch's 12 row tiles are split evenly: wave w owns row tile w in both output-channel passes of the W1 stage and
+//     row tile 8 + w / 2 in ONE of them (the two waves of a SIMD in different ones): 8 x requests per lane for every wave.
+// (A persistent form - 512 workgroups walking the tiles, the next tile's x fragments and W1 stages requested during the
+// epilogue - was built and measured: 156 vs 158 us.  The x requests cost their bandwidth, not their latency; the form was
+// dropped.  What it taught about hipcc is in profiles/r02_bottleneck128.md section 3.)
+template <typename T, int ABL = 0>
+__global__ void __launch_bounds__(512, 4) bottleneck128c_kernel(const Bneck128Params p) {
+  constexpr int C = 128, TH = 8, TW = 16, PW = TW + 2, PH = TH + 2, NPIX = PW * PH;   // 180 patch pixels
+  constexpr int NRT = (NPIX + 15) / 16;                             // 12 row tiles of the patch
+  constexpr int PLANE = NRT * 16 * 128;                             // 24576 B
+  constexpr int SLOT = 8192;
+  constexpr int SLD = 64 + 4;
+  constexpr int RW = 2;
+  constexpr int XS = (ABL & 4) ? 0 : 2 * RW;                        // shortcut requests per lane
+  static_assert(PW == 18 && NRT == 12, "the mul-shift below divides by 18; 8 + 4 row tiles");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sT = smem;
+  unsigned char* sR = smem + 2 * PLANE;
+  float* sB = reinterpret_cast<float*>(smem + PLANE + NPIX * 128);   // [256]: b1 then b2, in the spare rows of plane 1
+
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wmr = wave >> 1, wnc = wave & 1;      // 3x3 loop: tile rows 2 wmr, 2 wmr + 1, channels 64 wnc .. + 64
+  const int tiles = p.tiles_x * p.tiles_y;
+  const int rt1 = 8 + (wave >> 1), hp = (wave & 1) ^ (wave >> 2);   // second W1-stage unit: row tile rt1 in pass hp (the two waves of a SIMD take different passes)
+
+  // stage s: 0..3 = W1 rows 64 (s >> 1) .. + 64, k 64 (s & 1) .. + 64 (64 rows x 128 B); 4 + u = stage image u of W2 (128 rows x 64 B)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  const uint32_t tl = (uint32_t)(uintptr_t)(lds_void_t*)sT;
+  const int r1 = tid >> 3, g1 = (tid & 7) ^ (r1 & 7);
+  const unsigned char* src1 = p.w1 + ((long)r1 * p.kpad1 + g1 * 8) * 2;
+  const unsigned char* src2 = p.w2s + tid * 16;           // stage images: a linear copy, 1 KiB contiguous per wave
+  const int fb = lrow * 128 + ((lgrp ^ (lrow & 7)) << 4);
+  const int fb2 = (wnc * 64 + lrow) * 64 + ((lgrp ^ ((0x1320 >> (4 * ((lrow >> 2) & 3))) & 3)) << 4);
+#define BNC_STAGE(s_)                                                                                    \
+  {                                                                                                      \
+    const int ss_ = (s_);                                                                                \
+    const unsigned char* src_ = ss_ < 4 ? src1 + ((long)(ss_ >> 1) * 64 * p.kpad1 + (ss_ & 1) * 64) * 2  \
+                                        : src2 + (long)(ss_ - 4) * SLOT;                                 \
+    if constexpr (!(ABL & 8))                                                                            \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(sR + (ss_ & 3) * SLOT + wave * 1024), 16, 0, 0); \
+  }
+#define BNC_SYNC(n_)                                                                                     \
+  {                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    __builtin_amdgcn_s_waitcnt((n_) | 0x70);              /* vmcnt(n) lgkmcnt(0): a builtin, so the compiler's counter model sees it */ \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  }
+  const int tile = blockIdx.x;
+  const int b = tile / tiles, tt = tile - b * tiles;
+  const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const long img_pix = (long)b * p.H * p.W;
+  // x fragments: unconditional requests at clamped coordinates, masked below (row tile `wave`, row tile rt1)
+  gran_t a1n[2][4];
+  {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int q = (it == 0 ? wave : rt1) * 16 + lrow;
+      const int py = (q * 3641) >> 16, px = q - py * PW;
+      const int zy = min(max(y0 - 1 + py, 0), p.H - 1), zx = min(max(x0 - 1 + px, 0), p.W - 1);
+      const unsigned char* xp = p.x + ((img_pix + (long)zy * p.W + zx) * p.ldx + p.xoff + lgrp * 8) * 2;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if constexpr (ABL & 256) a1n[it][ks] = gran_t{0x3c003c00u + (unsigned)lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};   // probe: no x requests
+        else a1n[it][ks] = *reinterpret_cast<const gran_t*>(xp + ks * 64);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    BNC_STAGE(0)
+    BNC_STAGE(1)
+    BNC_STAGE(2)
+    __builtin_amdgcn_sched_barrier(0);
+    // biases last: their LDS store makes the compiler drain vmcnt (an LDS-DMA request is pending), which is what the first
+    // step needs anyway - x, the biases and stages 0-2 land together instead of one after the other
+    float bq = 0.0f;
+    if (tid < C) { if (p.b1 != nullptr) bq = p.b1[tid]; }
+    else if (tid < 2 * C) { if (p.b2 != nullptr) bq = p.b2[tid - C]; }
+    if (tid < 2 * C) sB[tid] = bq;
+  }
+  const int hp_t = hp;
+  {
+    BNC_SYNC(0)
+    // ---- hand-over: this tile's x fragments, zero outside the image / the patch
+    uint32_t keep[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int q = (it == 0 ? wave : rt1) * 16 + lrow;
+      const int py = (q * 3641) >> 16, px = q - py * PW;
+      keep[it] = (q < NPIX && (unsigned)(y0 - 1 + py) < (unsigned)p.H && (unsigned)(x0 - 1 + px) < (unsigned)p.W) ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        a1n[it][ks].x &= keep[it]; a1n[it][ks].y &= keep[it]; a1n[it][ks].z &= keep[it]; a1n[it][ks].w &= keep[it];
+      }
+    }
+
+    // ---- t^T = W1 x^T: output channels 0-63 (stages 0, 1), 64-127 (stages 2, 3), then bias + SiLU -> t patch
+#pragma unroll
+    for (int jh = 0; jh < 2; ++jh) {
+      f32x4_t acc1[2][4];
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc1[it][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const int s = jh * 2 + kt;
+        BNC_STAGE(s + 3)
+        gran_t wf[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          wf[j][0] = *reinterpret_cast<const gran_t*>(sR + (s & 3) * SLOT + j * 2048 + fb);
+          wf[j][1] = *reinterpret_cast<const gran_t*>(sR + (s & 3) * SLOT + j * 2048 + (fb ^ 64));
+        }
+        if constexpr (!(ABL & 1)) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1[0][j] = mma_granule<T>(wf[j][ks], a1n[0][kt * 2 + ks], acc1[0][j]);
+          if (hp_t == jh) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc1[1][j] = mma_granule<T>(wf[j][ks], a1n[1][kt * 2 + ks], acc1[1][j]);
+          }
+        }
+        BNC_SYNC(2)                                      // stage s + 1 landed (s + 2, s + 3 in flight); this slot's reads retired
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int q = (it == 0 ? wave : rt1) * 16 + lrow;
+        if ((it == 0 || hp_t == jh) && q < NPIX) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int cc = j * 16 + lgrp * 4;
+            const f32x4_t b1q = *reinterpret_cast<const f32x4_t*>(sB + jh * 64 + cc);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (ABL & 1) ? 0.0f : apply_act<(ABL & 512) ? CFT_ACT_NONE : CFT_ACT_SILU>(acc1[it][j][e] + b1q[e]);
+            uint2 w;
+            w.x = Elem<T>::pack2(v[0], v[1]) & keep[it];
+            w.y = Elem<T>::pack2(v[2], v[3]) & keep[it];
+            const uint32_t ta = tl + jh * PLANE + q * 128 + ((((cc >> 3) ^ (q & 7)) << 4) | ((cc & 7) << 1));
+            const unsigned long long wq = ((unsigned long long)w.y << 32) | w.x;
+            asm volatile("ds_write_b64 %0, %1" ::"v"(ta), "v"(wq) : "memory");
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // the whole t patch is visible
+
+    // ---- 3x3 conv of the t patch: step (tap, kq) = stage 4 + 4 tap + kq in slot kq; kq = plane * 2 + k half of the plane
+    f32x4_t acc[RW][4];
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // Software pipeline: step s issues stage s + 3, READS the fragments of stage s into register set kq & 1 and runs the MFMAs
+    // of step s - 1 from the other set under those reads; the counted wait + barrier at its end publishes stage s + 1.
+    gran_t af[2][RW], bf[2][4];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) af[1][i] = gran_t{0u, 0u, 0u, 0u};    // "step -1": zero products, the accumulators stay 0
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf[1][j] = gran_t{0u, 0u, 0u, 0u};
+#define BNC_READ(kq_)                                                                                    \
+    {                                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < RW; ++i) {                                                   \
+        const int q = qb + i * PW;                                                                       \
+        af[(kq_) & 1][i] = *reinterpret_cast<const gran_t*>(sT + ((kq_) >> 1) * PLANE + q * 128 + (((((kq_) & 1) * 4 + lgrp) ^ (q & 7)) << 4)); \
+      }                                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+        bf[(kq_) & 1][j] = *reinterpret_cast<const gran_t*>(sR + (kq_) * SLOT + j * 1024 + fb2);         \
+      __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }
+#define BNC_MMA(set_)                                                                                    \
+    {                                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < RW; ++i)                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
+          if constexpr (ABL & 2) { asm volatile("" ::"v"(af[set_][i]), "v"(bf[set_][j])); }              \
+          else acc[i][j] = mma_granule<T>(af[set_][i], bf[set_][j], acc[i][j]);                          \
+        }                                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }
+    gran_t rs[RW][2];
+#define BNC_FETCH_RS()                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < RW; ++i)                                                       \
+      _Pragma("unroll") for (int v = 0; v < 2; ++v) {                                                    \
+        const int it = lane + v * 64;                                                                    \
+        const int row = it >> 3, col = (it & 7) * 8;                                                     \
+        const int x = min(x0 + row, p.W - 1), y = min(y0 + wmr * RW + i, p.H - 1);                       \
+        if constexpr (XS != 0)                                                                           \
+          rs[i][v] = *reinterpret_cast<const gran_t*>(p.x + ((img_pix + (long)y * p.W + x) * p.ldx + p.xoff + wnc * 64 + col) * 2); \
+        else                                                                                             \
+          rs[i][v] = gran_t{0u, 0u, 0u, 0u};                                                             \
+      }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int tap = 0; tap < 8; ++tap) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const int qb = (wmr * RW + kh) * PW + kw + lrow;
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        BNC_STAGE(4 + tap * 4 + kq + 3)
+        BNC_READ(kq)
+        BNC_MMA((kq + 1) & 1)
+        BNC_SYNC(2)
+      }
+    }
+    {
+      const int qb = (wmr * RW + 2) * PW + 2 + lrow;     // tap 8: kh = kw = 2
+      BNC_STAGE(39)
+      // shortcut pixels: unconditional (clamped address) so that every wave has exactly XS more requests in flight
+      BNC_FETCH_RS()
+      __builtin_amdgcn_sched_barrier(0);
+      BNC_READ(0)
+      BNC_MMA(1)
+      BNC_SYNC(2 + XS)                                   // stage 37 landed; 38, 39 and the four shortcut requests may be in flight
+      BNC_READ(1)
+      BNC_MMA(0)
+      BNC_SYNC(1 + XS)
+      BNC_READ(2)
+      BNC_MMA(1)
+      BNC_SYNC(XS)
+      BNC_READ(3)
+      BNC_MMA(0)
+      BNC_MMA(1)
+    }
+#undef BNC_READ
+#undef BNC_MMA
+#undef BNC_FETCH_RS
+
+    // ---- epilogue: strip i = tile row 2 wmr + i, 16 pixels x 64 channels
+    if constexpr (ABL & 4) {
+#pragma unroll
+      for (int i = 0; i < RW; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else {
+      float b2v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b2v[j] = sB[C + wnc * 64 + j * 16 + lrow];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                     // every wave is past its last t read: the strips may overwrite the patch
+      float* stage = reinterpret_cast<float*>(sT) + wave * (16 * SLD);
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            stage[(lgrp * 4 + e) * SLD + j * 16 + lrow] = apply_act<(ABL & 512) ? CFT_ACT_NONE : CFT_ACT_SILU>(acc[i][j][e] + b2v[j]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const int it = lane + v * 64;
+          const int row = it >> 3, col = (it & 7) * 8;
+          const int x = x0 + row, y = y0 + wmr * RW + i;
+          if (x < p.W && y < p.H) {
+            const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col);
+            const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col + 4);
+            float o[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            if (p.shortcut) {
+              float rf[8];
+              Elem<T>::unpack(rs[i][v], rf);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] += rf[e];
+            }
+            *reinterpret_cast<gran_t*>(p.y + ((img_pix + (long)y * p.W + x) * p.ldy + p.yoff + wnc * 64 + col) * 2) = Elem<T>::pack(o);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+  }
+#undef BNC_STAGE
+#undef BNC_SYNC
+}
+
+// Stage-major image of the 3x3 weights for bottleneck128c_kernel: stage u (k = 32 u .. 32 u + 31 of every row) as the 8 KiB
+// the kernel wants in an LDS slot - row n at n * 64 B, k-granule kg of the stage in 16-byte slot kg ^ h((n / 4) & 3).
+__global__ void __launch_bounds__(256) bneck_pack_w2_kernel(const gran_t* __restrict__ w2, int kpad2, gran_t* __restrict__ out, int total) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int slot = i & 3, n = (i >> 2) & 127, u = i >> 9;
+  const int kg = slot ^ ((0x1320 >> (4 * ((n >> 2) & 3))) & 3);
+  out[i] = w2[(long)n * (kpad2 / 8) + u * 4 + kg];
+}
+
+extern "C" int cft_bottleneck_pack_w2(const void* w2, int kpad2, int c, void* w2_stages, int dtype, void* stream) {
+  CFT_REQUIRE(w2 && w2_stages, "cft_bottleneck_pack_w2: null pointer");
+  CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F16, "cft_bottleneck_pack_w2: dtype must be CFT_BF16 or CFT_F16");
+  CFT_REQUIRE(c == 128 && kpad2 == 9 * 128, "cft_bottleneck_pack_w2: 128 channels, kpad2 = 1152");
+  const int total = 36 * 128 * 4;
+  hipLaunchKernelGGL(bneck_pack_w2_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream),
+                     (const gran_t*)w2, kpad2, (gran_t*)w2_stages, total);
+  return cft_check_launch("bneck_pack_w2_kernel");
+}
+
 // CFT_BNECK128=persistent selects the one-workgroup-per-CU kernel; the default is the two-per-CU kernel.
 static bool bneck128_two_per_cu() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("CFT_BNECK128"); v = (e && e[0] == 'p') ? 0 : 1; }
   return v == 1;
 }
+// CFT_BNECK128=b selects the 16-KiB-K-tile kernel (bottleneck128b_kernel) for A/B runs; the default is the 4-slot-ring kernel.
+static bool bneck128_ring() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CFT_BNECK128"); v = (e && e[0] == 'b') ? 0 : 1; }
+  return v == 1;
+}
 
 extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, int kpad1, const float* b1,
-                              const void* w2, int kpad2, const float* b2, void* y, int ldy, int yoff,
+                              const void* w2, int kpad2, const void* w2_stages, const float* b2, void* y, int ldy, int yoff,
                               int B, int H, int W, int c, int shortcut, int dtype, void* stream) {
   CFT_REQUIRE(x && w1 && w2 && y, "cft_bottleneck: null pointer");
   CFT_REQUIRE(dtype == CFT_BF16 || dtype == CFT_F16, "cft_bottleneck: dtype must be CFT_BF16 or CFT_F16");
@@ -832,6 +1154,7 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
   if (c == 128 && bneck128_two_per_cu() && g_conv_variant != 9128 && g_conv_variant != 932) {   // variant 9128 / 932: the persistent kernel
     Bneck128Params q;
     q.x = (const unsigned char*)x; q.w1 = (const unsigned char*)w1; q.w2 = (const unsigned char*)w2;
+    q.w2s = (const unsigned char*)w2_stages;
     q.b1 = b1; q.b2 = b2; q.y = (unsigned char*)y;
     q.ldx = ldx; q.xoff = xoff; q.ldy = ldy; q.yoff = yoff; q.kpad1 = kpad1; q.kpad2 = kpad2;
     q.H = H; q.W = W; q.tiles_x = (W + 15) / 16; q.tiles_y = (H + 7) / 8; q.shortcut = shortcut ? 1 : 0;
@@ -845,10 +1168,30 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
       cft_allow_lds<&bottleneck128b_kernel<T_, NW_, ABL_>>(smemb);                                      \
       hipLaunchKernelGGL((bottleneck128b_kernel<T_, NW_, ABL_>), gridb, dim3(64 * NW_), smemb, sb_, q); \
     }
+#define BNC_LAUNCH(T_, ABL_)                                                                            \
+    {                                                                                                   \
+      cft_allow_lds<&bottleneck128c_kernel<T_, ABL_>>(smemb);                                           \
+      hipLaunchKernelGGL((bottleneck128c_kernel<T_, ABL_>), gridb, dim3(512), smemb, sb_, q);           \
+    }
+    // Default: the 4-slot-ring kernel when the caller supplies the stage-major weights, else the 16-KiB-K-tile kernel.
+    // Variants: 9100 (or CFT_BNECK128=b) = the 16-KiB-K-tile kernel, 9004 = its 4-wave form, 92xx / 94xx / 97xx probes.
+    const int var = g_conv_variant;
+    const bool ring = q.w2s != nullptr && bneck128_ring() && var != 9100 && var != 9004 && !(var >= 901 && var <= 916) && !(var >= 9014 && var <= 9084);
     if (dtype == CFT_F16) {
-      if (g_conv_variant == 9004) BNB_LAUNCH(f16_t, 4, 0) else BNB_LAUNCH(f16_t, 8, 0)
+      if (!ring) { if (var == 9004) BNB_LAUNCH(f16_t, 4, 0) else BNB_LAUNCH(f16_t, 8, 0) }
+      else BNC_LAUNCH(f16_t, 0)
+    } else if (ring) {
+      switch (var) {
+        case 9201: BNC_LAUNCH(uint16_t, 1) break;           // probes: no W1-stage MFMAs / no 3x3 MFMAs / no epilogue / no weight DMA
+        case 9202: BNC_LAUNCH(uint16_t, 2) break;
+        case 9204: BNC_LAUNCH(uint16_t, 4) break;
+        case 9208: BNC_LAUNCH(uint16_t, 8) break;
+        case 9456: BNC_LAUNCH(uint16_t, 256) break;         // no x requests / no SiLU
+        case 9712: BNC_LAUNCH(uint16_t, 512) break;
+        default: BNC_LAUNCH(uint16_t, 0) break;
+      }
     } else {
-      switch (g_conv_variant) {
+      switch (var) {
         case 901: BNB_LAUNCH(uint16_t, 8, 1) break;
         case 902: BNB_LAUNCH(uint16_t, 8, 2) break;
         case 904: BNB_LAUNCH(uint16_t, 8, 4) break;
@@ -863,6 +1206,7 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
       }
     }
 #undef BNB_LAUNCH
+#undef BNC_LAUNCH
     return cft_check_launch("bottleneck128b_kernel");
   }
   if (c == 128) {

@@ -102,6 +102,7 @@ class PackedConv:
     k: int
     s: int
     flops_per_row: float = 0.0   # algorithmic 2*N*K of the unpadded layer (roofline accounting)
+    w_stages: Optional[torch.Tensor] = None   # stage-major image of w for cft_bottleneck (128-channel 3x3), built on first use
 
 
 def fold_bn(weight, bn_weight, bn_bias, running_mean, running_var, eps):
@@ -236,8 +237,13 @@ def bottleneck(x, pk1, pk2, shortcut, out=None):
         raise ValueError(f"bottleneck: out has shape {tuple(out.shape)}, expected {(B, C, H, W)}")
     ldy = _view_ld(out, "bottleneck out")
     lib = _lib.load()
+    if C == 128 and pk2.w_stages is None:   # one-time: the 3x3 weights as 36 contiguous 8-KiB stage images (cft_bottleneck_pack_w2)
+        pk2.w_stages = torch.empty_like(pk2.w)
+        _lib.check(lib.cft_bottleneck_pack_w2(pk2.w.data_ptr(), pk2.kpad, C, pk2.w_stages.data_ptr(), _dt(x.dtype), _stream()),
+                   "cft_bottleneck_pack_w2")
     args = (x.data_ptr(), ldx, 0, pk1.w.data_ptr(), pk1.kpad, pk1.bias.data_ptr() if pk1.bias is not None else None,
-            pk2.w.data_ptr(), pk2.kpad, pk2.bias.data_ptr() if pk2.bias is not None else None,
+            pk2.w.data_ptr(), pk2.kpad, pk2.w_stages.data_ptr() if pk2.w_stages is not None else None,
+            pk2.bias.data_ptr() if pk2.bias is not None else None,
             out.data_ptr(), ldy, 0, B, H, W, C, 1 if shortcut else 0, _dt(x.dtype), _stream())
     if _launch_log is None:
         st = lib.cft_bottleneck(*args)

@@ -375,9 +375,9 @@ def test_bottleneck_fused_is_bit_identical(dev, shortcut, hw, dtype, C):
     assert torch.equal(d[:, :C].float().cpu(), x), "input slice untouched"
     with pytest.raises(RuntimeError):
         ops.bottleneck(xin, pk1, pk2, shortcut, out=xin)         # in-place is refused (halo reads)
-    if C == 128:      # the other implementations of the same kernel: persistent one-workgroup-per-CU (9128), 4-wave workgroups (9004)
+    if C == 128:      # the other implementations of the same kernel: persistent one-workgroup-per-CU (9128), 16-KiB K tiles with 8 / 4 waves (9100 / 9004)
         from msod_amd import _lib
-        for variant in (9128, 9004):
+        for variant in (9128, 9004, 9100):
             _lib.load().cft_set_conv_variant(variant)
             try:
                 other = ops.bottleneck(xin, pk1, pk2, shortcut)
@@ -387,6 +387,29 @@ def test_bottleneck_fused_is_bit_identical(dev, shortcut, hw, dtype, C):
             assert torch.equal(other.float().cpu(), two.float().cpu()), variant
     ref = O.bottleneck(sd, "m.", x, shortcut)
     assert rel_err(to_cpu_f32(fused), ref) < 2 * tol(dtype)   # two 16-bit roundings (hidden tensor, output)
+
+
+@pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
+def test_bottleneck128_many_tiles_per_workgroup(dev, dtype):
+    """More tiles than workgroup slots (12 x 50 = 600 > 512, so workgroups start while others are mid-tile), at the
+    BASELINE map size of the 128-channel stage: both two-per-CU kernels equal the two cft_conv2d launches bit for bit."""
+    from msod_amd import _lib, ops
+    C, B, H, W = 128, 12, 80, 80
+    g = torch.Generator().manual_seed(5)
+    pk1 = ops.pack_conv(torch.randn(C, C, 1, 1, generator=g) / C ** 0.5, torch.randn(C, generator=g) * 0.1, dtype, device=dev)
+    pk2 = ops.pack_conv(torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5), torch.randn(C, generator=g) * 0.1, dtype, device=dev)
+    x = ops.new_nhwc(B, H, W, C, dtype, dev)
+    x.copy_(torch.randn(x.shape, generator=g).to(dev))
+    two = ops.conv2d(ops.conv2d(x, pk1, 1), pk2, 1, residual=x)
+    lib = _lib.load()
+    for variant in (0, 9100):
+        lib.cft_set_conv_variant(variant)
+        try:
+            y = ops.bottleneck(x, pk1, pk2, True)
+            torch.cuda.synchronize()
+        finally:
+            lib.cft_set_conv_variant(0)
+        assert torch.equal(y.float().cpu(), two.float().cpu()), variant
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)

@@ -101,7 +101,7 @@ def test_pack_conv_layout(dtype):
 def test_c_abi_exports_every_declared_symbol():
     """The shared library must load (no GPU needed) and export exactly what include/cft_hip.h declares."""
     lib = _lib.load()
-    assert lib.cft_abi_version() == 2
+    assert lib.cft_abi_version() == 3
     header = open(os.path.join(ROOT, "include", "cft_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:int|long|const char\*)\s+(cft_\w+)\s*\(", header, re.M))
     assert declared == set(_lib.SIGNATURES) | {"cft_last_error"}, declared ^ (set(_lib.SIGNATURES) | {"cft_last_error"})
@@ -124,12 +124,14 @@ def test_bad_arguments_return_error_codes_without_gpu():
     st = lib.cft_focus_conv(17, 1, 3 * 64 * 64, 64 * 64, 64, 1.0 / 255, 16, 192, None, 16, 64, 0, 1, 64, 64, 64, 1, 0, None)
     assert st == -1 and b"pixel-pair" in lib.cft_last_error()
     # fused Bottleneck: 64 / 128 channels only, and never in place (it reads a halo of x)
-    st = lib.cft_bottleneck(4096, 256, 0, 16, 256, None, 16, 2304, None, 1 << 20, 256, 0, 1, 8, 8, 256, 1, 0, None)
+    st = lib.cft_bottleneck(4096, 256, 0, 16, 256, None, 16, 2304, None, None, 1 << 20, 256, 0, 1, 8, 8, 256, 1, 0, None)
     assert st == -1 and b"64 and 128 channels" in lib.cft_last_error()
-    st = lib.cft_bottleneck(4096, 64, 0, 16, 64, None, 16, 576, None, 4096, 64, 0, 1, 8, 8, 64, 1, 0, None)
+    st = lib.cft_bottleneck(4096, 64, 0, 16, 64, None, 16, 576, None, None, 4096, 64, 0, 1, 8, 8, 64, 1, 0, None)
     assert st == -1 and b"overlaps the input" in lib.cft_last_error()
-    st = lib.cft_bottleneck(4096, 128, 0, 16, 64, None, 16, 576, None, 4096 + 64, 128, 0, 1, 8, 8, 64, 1, 0, None)
+    st = lib.cft_bottleneck(4096, 128, 0, 16, 64, None, 16, 576, None, None, 4096 + 64, 128, 0, 1, 8, 8, 64, 1, 0, None)
     assert st == -1 and b"overlaps" in lib.cft_last_error()       # slices of one buffer that share channels [32,64)
+    st = lib.cft_bottleneck_pack_w2(16, 576, 64, 32, 0, None)     # stage images exist for the 128-channel kernel only
+    assert st == -1 and b"128 channels" in lib.cft_last_error()
 
 
 def test_no_cpu_fallback():

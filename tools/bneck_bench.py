@@ -14,16 +14,20 @@ import msod_amd  # noqa: E402,F401
 from msod_amd import _lib, ops  # noqa: E402
 
 
-def timeit(fn, iters=20):
-    fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
+def timeit(fn, iters=20, repeats=3):
+    for _ in range(3):
         fn()
-    e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / iters
+    best = 1e30
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
+    return best
 
 
 def main():
