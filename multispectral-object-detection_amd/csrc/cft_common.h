@@ -119,7 +119,19 @@ __device__ __forceinline__ void lds_barrier() {
 template <int ACT>
 __device__ __forceinline__ float apply_act(float v) {
   if constexpr (ACT == CFT_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));   // x*sigmoid(x): v_exp + v_rcp
-  if constexpr (ACT == CFT_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+  if constexpr (ACT == CFT_ACT_GELU) {
+    // exact-erf GELU (reference nn.GELU(), models/common.py:498) = max(v, 0) - 0.5 |v| erfc(|v| / sqrt 2), erfc by Abramowitz &
+    // Stegun 7.1.26 (|error| <= 1.5e-7, no cancellation in the negative tail): 14 VALU instructions, two of them
+    // transcendental, against ~35 for erff() - the fc1 epilogue of the GPT blocks is VALU-bound (profiles/r02_bottleneck128.md section 3)
+    const float z = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(z * (z * -1.4426950408889634f));
+    float q = fmaf(1.061405429f, t, -1.453152027f);
+    q = fmaf(q, t, 1.421413741f);
+    q = fmaf(q, t, -0.284496736f);
+    q = fmaf(q, t, 0.254829592f);
+    return fmaf(-0.5f * fabsf(v), q * t * e, fmaxf(v, 0.0f));
+  }
   return v;
 }
 
