@@ -206,9 +206,9 @@ def conv2d(x, pk, act, residual=None, out=None, out_dtype=None):
 
 
 # cft_bottleneck covers 64 channels (3x3 weights LDS-resident, one workgroup per CU) and 128 channels (activation patch
-# resident, weights streamed; two workgroups per CU: 187 vs 234 us for the two launches it replaces, +2.9 % pairs/s on
-# the forward - profiles/r02_bottleneck128.md).  CFT_FUSE128=0 in the environment restores the two-launch path for the
-# 128-channel stage (A/B runs); CFT_BNECK128=persistent selects the one-workgroup-per-CU implementation of the kernel.
+# resident, weights streamed through a 4-slot LDS ring; two workgroups per CU: 147-173 vs 220-234 us for the two launches it
+# replaces - profiles/r02_bottleneck128.md).  CFT_FUSE128=0 in the environment restores the two-launch path for the
+# 128-channel stage (A/B runs); CFT_BNECK128=b / persistent select the earlier implementations of the kernel.
 import os as _os
 FUSED_BOTTLENECK_WIDTHS = (64,) if _os.environ.get("CFT_FUSE128", "1") == "0" else (64, 128)
 
