@@ -126,8 +126,12 @@ def cpu_baseline(cfg, sd, height, width, batch, budget_s=30.0):
         for t in sweep:
             if results and spent + min(results.values()) > budget_s * 0.7:
                 break
+            if len(results) >= 2 and list(results.values())[-1] > 1.5 * min(results.values()):
+                break                                     # past the optimum: wider only gets slower (256 threads: 200 s per forward)
             torch.set_num_threads(t)
+            t0 = time.perf_counter()
             om(sd, rgb[:1], ir[:1])                       # thread-pool warm-up at this width
+            spent += time.perf_counter() - t0
             t0 = time.perf_counter()
             om(sd, rgb, ir)
             results[t] = time.perf_counter() - t0

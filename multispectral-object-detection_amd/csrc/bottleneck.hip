@@ -1098,6 +1098,263 @@ __global__ void __launch_bounds__(512, 4) bottleneck128c_kernel(const Bneck128Pa
 #undef BNC_SYNC
 }
 
+// ------------------------------------------------------------------------------------ 64 channels, two per CU, 4-slot ring
+// The recipe of bottleneck128c_kernel for the 64-channel stage (160 x 160 maps): the activation patch of a 16 x 16-pixel tile
+// stays in LDS (18 x 18 x 128 B = 42 KiB, one 64-channel plane) and the weights stream - W1 as one stage, W2 as one stage per
+// tap (64 rows x 128 B = 8 KiB, straight from the cft_conv2d layout: a row's 64 k are one cache line) - through a 4-slot
+// ring three stages ahead.  42 + 32 KiB: two workgroups per CU, where bottleneck_kernel (3x3 weights resident, 117 KiB) has
+// one whose 16 waves run their SiLU passes and their MFMAs in lock step.  Wave w owns tile rows 2 w, 2 w + 1 and all 64
+// channels; per tap it reads 4 + 8 fragments for 16 MFMAs, the second k half under the MFMAs of the first.
+template <typename T, int ABL = 0>
+__global__ void __launch_bounds__(512, 4) bottleneck64r_kernel(const Bneck128Params p) {
+  constexpr int C = 64, TS = 16, PW = TS + 2, NPIX = PW * PW;       // 324 patch pixels
+  constexpr int NRT = (NPIX + 15) / 16;                             // 21 row tiles of the patch
+  constexpr int PATCH = NRT * 16 * 128;                             // 43008 B
+  constexpr int SLOT = 8192;
+  constexpr int SLD = 64 + 4;
+  constexpr int RW = 2, RT1 = 3;
+  static_assert(PW == 18, "the mul-shift below divides by 18");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sT = smem;
+  unsigned char* sR = smem + PATCH;
+  float* sB = reinterpret_cast<float*>(smem + NPIX * 128);           // [128]: b1 then b2, in the spare rows of the patch
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  const int tiles = p.tiles_x * p.tiles_y;
+  const int b = blockIdx.x / tiles, tt = blockIdx.x - b * tiles;
+  const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+  const int y0 = ty * TS, x0 = tx * TS;
+  const long img_pix = (long)b * p.H * p.W;
+  const uint32_t tl = (uint32_t)(uintptr_t)(lds_void_t*)sT;
+
+  // stage 0 = W1, stage 1 + tap = W2[:, 64 tap .. 64 tap + 63]: 64 rows x 128 B, k-granule g of row r in slot g ^ (r & 7)
+  const int r1 = tid >> 3, g1 = (tid & 7) ^ (r1 & 7);
+  const unsigned char* src1 = p.w1 + ((long)r1 * p.kpad1 + g1 * 8) * 2;
+  const unsigned char* src2 = p.w2 + ((long)r1 * p.kpad2 + g1 * 8) * 2;
+#define BNR_STAGE(s_)                                                                                    \
+  {                                                                                                      \
+    const int ss_ = (s_);                                                                                \
+    const unsigned char* src_ = ss_ == 0 ? src1 : src2 + (long)(ss_ - 1) * 128;                          \
+    if constexpr (!(ABL & 8))                                                                            \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(sR + (ss_ & 3) * SLOT + wave * 1024), 16, 0, 0); \
+  }
+#define BNR_SYNC(n_)                                                                                     \
+  {                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    __builtin_amdgcn_s_waitcnt((n_) | 0x70);              /* vmcnt(n) lgkmcnt(0) */                      \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  }
+  const int fb = lrow * 128 + ((lgrp ^ (lrow & 7)) << 4);
+
+  // x fragments: row tiles wave, wave + 8, wave + 16 (the last one for waves 0-4), clamped coordinates, masked below
+  gran_t a1[RT1][2];
+  uint32_t keep[RT1];
+#pragma unroll
+  for (int it = 0; it < RT1; ++it) {
+    const int q = (wave + 8 * it) * 16 + lrow;
+    const int py = (q * 3641) >> 16, px = q - py * PW;
+    const int zy = min(max(y0 - 1 + py, 0), p.H - 1), zx = min(max(x0 - 1 + px, 0), p.W - 1);
+    keep[it] = (q < NPIX && (unsigned)(y0 - 1 + py) < (unsigned)p.H && (unsigned)(x0 - 1 + px) < (unsigned)p.W) ? 0xffffffffu : 0u;
+    const unsigned char* xp = p.x + ((img_pix + (long)zy * p.W + zx) * p.ldx + p.xoff + lgrp * 8) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      gran_t t = {0u, 0u, 0u, 0u};
+      if (wave + 8 * it < NRT) t = *reinterpret_cast<const gran_t*>(xp + ks * 64);
+      a1[it][ks] = t;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  BNR_STAGE(0)
+  BNR_STAGE(1)
+  BNR_STAGE(2)
+  __builtin_amdgcn_sched_barrier(0);
+  {   // biases last: their LDS store makes the compiler drain vmcnt, which is what the first step needs anyway
+    float bq = 0.0f;
+    if (tid < C) { if (p.b1 != nullptr) bq = p.b1[tid]; }
+    else if (tid < 2 * C) { if (p.b2 != nullptr) bq = p.b2[tid - C]; }
+    if (tid < 2 * C) sB[tid] = bq;
+  }
+  BNR_SYNC(0)
+#pragma unroll
+  for (int it = 0; it < RT1; ++it)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      a1[it][ks].x &= keep[it]; a1[it][ks].y &= keep[it]; a1[it][ks].z &= keep[it]; a1[it][ks].w &= keep[it];
+    }
+
+  // ---- t^T = W1 x^T (stage 0), bias + SiLU -> t patch
+  {
+    f32x4_t acc1[RT1][4];
+#pragma unroll
+    for (int it = 0; it < RT1; ++it)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc1[it][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    BNR_STAGE(3)
+    gran_t wf[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      wf[j][0] = *reinterpret_cast<const gran_t*>(sR + j * 2048 + fb);
+      wf[j][1] = *reinterpret_cast<const gran_t*>(sR + j * 2048 + (fb ^ 64));
+    }
+    if constexpr (!(ABL & 1)) {
+#pragma unroll
+      for (int it = 0; it < RT1; ++it)
+        if (wave + 8 * it < NRT) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1[it][j] = mma_granule<T>(wf[j][ks], a1[it][ks], acc1[it][j]);
+        }
+    }
+    BNR_SYNC(2)                                          // stage 1 landed (2, 3 in flight); slot 0's reads retired
+#pragma unroll
+    for (int it = 0; it < RT1; ++it) {
+      const int q = (wave + 8 * it) * 16 + lrow;
+      if (wave + 8 * it < NRT && q < NPIX) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cc = j * 16 + lgrp * 4;
+          const f32x4_t b1q = *reinterpret_cast<const f32x4_t*>(sB + cc);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (ABL & 1) ? 0.0f : apply_act<CFT_ACT_SILU>(acc1[it][j][e] + b1q[e]);
+          uint2 w;
+          w.x = Elem<T>::pack2(v[0], v[1]) & keep[it];
+          w.y = Elem<T>::pack2(v[2], v[3]) & keep[it];
+          const uint32_t ta = tl + q * 128 + ((((cc >> 3) ^ (q & 7)) << 4) | ((cc & 7) << 1));
+          const unsigned long long wq = ((unsigned long long)w.y << 32) | w.x;
+          asm volatile("ds_write_b64 %0, %1" ::"v"(ta), "v"(wq) : "memory");
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                         // the whole t patch is visible
+
+  // ---- 3x3 conv of the t patch: step tap = stage 1 + tap in slot (1 + tap) & 3, two k halves per step
+  f32x4_t acc[RW][4];
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  gran_t af[2][RW], bf[2][4];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) af[1][i] = gran_t{0u, 0u, 0u, 0u};      // "step -1": zero products
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bf[1][j] = gran_t{0u, 0u, 0u, 0u};
+#define BNR_READ(slot_, ks_)                                                                             \
+  {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < RW; ++i) {                                                     \
+      const int q = qb + i * PW;                                                                         \
+      af[ks_][i] = *reinterpret_cast<const gran_t*>(sT + q * 128 + ((((ks_) * 4 + lgrp) ^ (q & 7)) << 4)); \
+    }                                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+      bf[ks_][j] = *reinterpret_cast<const gran_t*>(sR + (slot_) * SLOT + j * 2048 + ((ks_) ? (fb ^ 64) : fb)); \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  }
+#define BNR_MMA(set_)                                                                                    \
+  {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < RW; ++i)                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
+        if constexpr (ABL & 2) { asm volatile("" ::"v"(af[set_][i]), "v"(bf[set_][j])); }                \
+        else acc[i][j] = mma_granule<T>(af[set_][i], bf[set_][j], acc[i][j]);                            \
+      }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  }
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int qb = (wave * RW + kh) * PW + kw + lrow;
+    if (tap + 4 <= 9) BNR_STAGE(tap + 4)
+    BNR_READ((1 + tap) & 3, 0)
+    BNR_MMA(1)
+    BNR_READ((1 + tap) & 3, 1)
+    BNR_MMA(0)
+    // stage 2 + tap must have landed; younger: stages 3 + tap, 4 + tap (while they exist)
+    if (tap <= 5) { BNR_SYNC(2) }
+    else if (tap == 6) { BNR_SYNC(1) }
+    else if (tap == 7) { BNR_SYNC(0) }
+  }
+  BNR_MMA(1)
+#undef BNR_READ
+#undef BNR_MMA
+#undef BNR_STAGE
+#undef BNR_SYNC
+
+  // ---- epilogue: strip i = tile row 2 wave + i, 16 pixels x 64 channels
+  if constexpr (ABL & 4) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+  float b2v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b2v[j] = sB[C + j * 16 + lrow];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                         // every wave is past its last t / ring read: strips and x centre may overwrite them
+  // The shortcut is x at the tile's own pixels - which this workgroup already holds: the interior of the patch whose x
+  // fragments fed the W1 stage.  They are parked in the (now dead) 32 KiB of the ring, pixel-major, instead of being read
+  // from memory a second time (210 MB per launch at 160 x 160, a third of the kernel's HBM traffic).
+  if (p.shortcut) {
+    int lane_e;                                          // recomputed: carried from the prologue these indices would be spilled
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int lrow_e = lane_e & 15, lgrp_e = lane_e >> 4;
+#pragma unroll
+    for (int it = 0; it < RT1; ++it) {
+      const int q = (wave + 8 * it) * 16 + lrow_e;
+      const int py = (q * 3641) >> 16, px = q - py * PW;
+      if (wave + 8 * it < NRT && py >= 1 && py <= TS && px >= 1 && px <= TS) {
+        const int c = (py - 1) * TS + (px - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          *reinterpret_cast<gran_t*>(sR + c * 128 + (((ks * 4 + lgrp_e) ^ (c & 7)) << 4)) = a1[it][ks];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  float* stage = reinterpret_cast<float*>(sT) + wave * (16 * SLD);
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        stage[(lgrp * 4 + e) * SLD + j * 16 + lrow] = apply_act<CFT_ACT_SILU>(acc[i][j][e] + b2v[j]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int it = lane + v * 64;
+      const int row = it >> 3, col = (it & 7) * 8;
+      const int x = x0 + row, y = y0 + wave * RW + i;
+      if (x < p.W && y < p.H) {
+        const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col);
+        const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col + 4);
+        float o[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        if (p.shortcut) {
+          const int c = (wave * RW + i) * TS + row;
+          const gran_t rsv = *reinterpret_cast<const gran_t*>(sR + c * 128 + (((it & 7) ^ (c & 7)) << 4));
+          float rf[8];
+          Elem<T>::unpack(rsv, rf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += rf[e];
+        }
+        *reinterpret_cast<gran_t*>(p.y + ((img_pix + (long)y * p.W + x) * p.ldy + p.yoff + col) * 2) = Elem<T>::pack(o);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 // Stage-major image of the 3x3 weights for bottleneck128c_kernel: stage u (k = 32 u .. 32 u + 31 of every row) as the 8 KiB
 // the kernel wants in an LDS slot - row n at n * 64 B, k-granule kg of the stage in 16-byte slot kg ^ h((n / 4) & 3).
 __global__ void __launch_bounds__(256) bneck_pack_w2_kernel(const gran_t* __restrict__ w2, int kpad2, gran_t* __restrict__ out, int total) {
@@ -1122,6 +1379,12 @@ extern "C" int cft_bottleneck_pack_w2(const void* w2, int kpad2, int c, void* w2
 static bool bneck128_two_per_cu() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("CFT_BNECK128"); v = (e && e[0] == 'p') ? 0 : 1; }
+  return v == 1;
+}
+// CFT_BNECK64=resident selects bottleneck_kernel (3x3 weights LDS-resident, one workgroup per CU) for the 64-channel stage.
+static bool bneck64_ring() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CFT_BNECK64"); v = (e && e[0] == 'r') ? 0 : 1; }
   return v == 1;
 }
 // CFT_BNECK128=b selects the 16-KiB-K-tile kernel (bottleneck128b_kernel) for A/B runs; the default is the 4-slot-ring kernel.
@@ -1246,6 +1509,36 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
     }
 #undef BN128_LAUNCH
     return cft_check_launch("bottleneck128_kernel");
+  }
+  if (bneck64_ring() && g_conv_variant != 9640 && !(g_conv_variant >= 901 && g_conv_variant <= 907)) {   // 9640 / CFT_BNECK64=resident: the weights-resident kernel
+    Bneck128Params q;
+    q.x = (const unsigned char*)x; q.w1 = (const unsigned char*)w1; q.w2 = (const unsigned char*)w2; q.w2s = nullptr;
+    q.b1 = b1; q.b2 = b2; q.y = (unsigned char*)y;
+    q.ldx = ldx; q.xoff = xoff; q.ldy = ldy; q.yoff = yoff; q.kpad1 = kpad1; q.kpad2 = kpad2;
+    q.H = H; q.W = W; q.tiles_x = (W + 15) / 16; q.tiles_y = (H + 15) / 16; q.shortcut = shortcut ? 1 : 0;
+    CFT_REQUIRE((long)B * q.tiles_x * q.tiles_y < (1L << 31), "cft_bottleneck: too many tiles");
+    q.ntiles = B * q.tiles_x * q.tiles_y; q.dbg = nullptr;
+    constexpr int smemr = 21 * 16 * 128 + 4 * 8192;
+    const dim3 gridr(q.ntiles);
+    hipStream_t sr_ = as_stream(stream);
+#define BNR_LAUNCH(T_, ABL_)                                                                            \
+    {                                                                                                   \
+      cft_allow_lds<&bottleneck64r_kernel<T_, ABL_>>(smemr);                                            \
+      hipLaunchKernelGGL((bottleneck64r_kernel<T_, ABL_>), gridr, dim3(512), smemr, sr_, q);            \
+    }
+    if (dtype == CFT_F16) {
+      BNR_LAUNCH(f16_t, 0)
+    } else {
+      switch (g_conv_variant) {   // probes: no W1-stage MFMAs / no 3x3 MFMAs / no epilogue / no weight DMA
+        case 9601: BNR_LAUNCH(uint16_t, 1) break;
+        case 9602: BNR_LAUNCH(uint16_t, 2) break;
+        case 9604: BNR_LAUNCH(uint16_t, 4) break;
+        case 9608: BNR_LAUNCH(uint16_t, 8) break;
+        default: BNR_LAUNCH(uint16_t, 0) break;
+      }
+    }
+#undef BNR_LAUNCH
+    return cft_check_launch("bottleneck64r_kernel");
   }
   BneckParams p;
   p.x = (const unsigned char*)x; p.w1 = (const unsigned char*)w1; p.w2 = (const unsigned char*)w2;

@@ -385,6 +385,15 @@ def test_bottleneck_fused_is_bit_identical(dev, shortcut, hw, dtype, C):
             finally:
                 _lib.load().cft_set_conv_variant(0)
             assert torch.equal(other.float().cpu(), two.float().cpu()), variant
+    if C == 64:       # the other implementation: 3x3 weights LDS-resident, one workgroup per CU (9640)
+        from msod_amd import _lib
+        _lib.load().cft_set_conv_variant(9640)
+        try:
+            other = ops.bottleneck(xin, pk1, pk2, shortcut)
+            torch.cuda.synchronize()
+        finally:
+            _lib.load().cft_set_conv_variant(0)
+        assert torch.equal(other.float().cpu(), two.float().cpu()), 9640
     ref = O.bottleneck(sd, "m.", x, shortcut)
     assert rel_err(to_cpu_f32(fused), ref) < 2 * tol(dtype)   # two 16-bit roundings (hidden tensor, output)
 
