@@ -245,7 +245,7 @@ def main():
                                    f"{args.size}x{args.size}, {args.batch} pairs/GPU, BN folded, pre-NMS detections",
                        "pairs_per_gpu": args.batch, "image_size": args.size, "parallelism": f"batch-shard x{world}",
                        "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap},
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear family; incl. the dedicated Focus and 64-channel Bottleneck kernels, 8 of the launches)",
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear family; incl. the dedicated Focus kernel and the fused 64- / 128-channel Bottleneck kernels: 2 + 27 launches of the cfg3 forward)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic_from_profile(args, n_launch, abytes), "launches_per_step": n_launch,
                          "event_bracket_overhead_us": round(ovh * 1e6, 2),
