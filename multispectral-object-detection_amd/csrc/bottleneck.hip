@@ -605,7 +605,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) bottleneck128b_kernel(const B
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int wmr = wave >> 1, wnc = wave & 1;      // 3x3 loop: tile rows RW wmr .. + RW, channels 64 wnc .. + 64
   const int tiles = p.tiles_x * p.tiles_y;
-  const int b = blockIdx.x / tiles, tt = blockIdx.x - b * tiles;
+  // XCD-aware tile assignment (bijective for any grid size): workgroup ids go round-robin over the 8 XCDs, so consecutive
+  // LOGICAL tiles - spatial neighbours that share halo pixels - are given to one XCD and meet in its L2
+  const int nb_ = gridDim.x, bid_ = blockIdx.x;
+  const int xq_ = nb_ >> 3, xr_ = nb_ & 7, xcd_ = bid_ & 7, xslot_ = bid_ >> 3;
+  const int ltile = (xcd_ < xr_ ? xcd_ * (xq_ + 1) : xr_ * (xq_ + 1) + (xcd_ - xr_) * xq_) + xslot_;
+  const int b = ltile / tiles, tt = ltile - b * tiles;
   const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
   const long img_pix = (long)b * p.H * p.W;
@@ -863,7 +868,12 @@ __global__ void __launch_bounds__(512, 4) bottleneck128c_kernel(const Bneck128Pa
     __builtin_amdgcn_s_barrier();                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                   \
   }
-  const int tile = blockIdx.x;
+  // XCD-aware tile assignment (bijective for any grid size): workgroup ids go round-robin over the 8 XCDs, so consecutive
+  // LOGICAL tiles - spatial neighbours that share halo pixels - are given to one XCD and meet in its L2
+  const int nb_ = gridDim.x, bid_ = blockIdx.x;
+  const int xq_ = nb_ >> 3, xr_ = nb_ & 7, xcd_ = bid_ & 7, xslot_ = bid_ >> 3;
+  const int ltile = (xcd_ < xr_ ? xcd_ * (xq_ + 1) : xr_ * (xq_ + 1) + (xcd_ - xr_) * xq_) + xslot_;
+  const int tile = ltile;
   const int b = tile / tiles, tt = tile - b * tiles;
   const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
@@ -1123,7 +1133,12 @@ __global__ void __launch_bounds__(512, 4) bottleneck64r_kernel(const Bneck128Par
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int tiles = p.tiles_x * p.tiles_y;
-  const int b = blockIdx.x / tiles, tt = blockIdx.x - b * tiles;
+  // XCD-aware tile assignment (bijective for any grid size): workgroup ids go round-robin over the 8 XCDs, so consecutive
+  // LOGICAL tiles - spatial neighbours that share halo pixels - are given to one XCD and meet in its L2
+  const int nb_ = gridDim.x, bid_ = blockIdx.x;
+  const int xq_ = nb_ >> 3, xr_ = nb_ & 7, xcd_ = bid_ & 7, xslot_ = bid_ >> 3;
+  const int ltile = (xcd_ < xr_ ? xcd_ * (xq_ + 1) : xr_ * (xq_ + 1) + (xcd_ - xr_) * xq_) + xslot_;
+  const int b = ltile / tiles, tt = ltile - b * tiles;
   const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
   const int y0 = ty * TS, x0 = tx * TS;
   const long img_pix = (long)b * p.H * p.W;
