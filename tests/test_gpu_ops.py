@@ -399,6 +399,28 @@ def test_bottleneck_fused_is_bit_identical(dev, shortcut, hw, dtype, C):
 
 
 @pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
+def test_bottleneck_pack_w2_stage_images(dev, dtype):
+    """cft_bottleneck_pack_w2: stage u of the image is k = 32u .. 32u + 31 of every row, row n at n * 64 B, k-granule kg of
+    the stage in 16-byte slot kg ^ h((n / 4) & 3), h = (0, 2, 3, 1) - the order the 128-channel kernel keeps a stage in LDS."""
+    from msod_amd import _lib, ops
+    C = 128
+    g = torch.Generator().manual_seed(11)
+    pk2 = ops.pack_conv(torch.randn(C, C, 3, 3, generator=g), None, dtype, device=dev)
+    stages = torch.empty_like(pk2.w)
+    lib = _lib.load()
+    _lib.check(lib.cft_bottleneck_pack_w2(pk2.w.data_ptr(), pk2.kpad, C, stages.data_ptr(), ops._dt(dtype), None), "pack")
+    torch.cuda.synchronize()
+    w = pk2.w.cpu().view(torch.int16).view(C, 36, 4, 8)                  # [n][u][kg][8]
+    got = stages.cpu().view(torch.int16).view(36, C, 4, 8)              # [u][n][slot][8]
+    h = torch.tensor([0, 2, 3, 1])
+    n = torch.arange(C)
+    for slot in range(4):
+        kg = slot ^ h[(n >> 2) & 3]                                      # [n]
+        want = w[n, :, kg, :].permute(1, 0, 2)                           # [u][n][8]
+        assert torch.equal(got[:, :, slot, :], want), slot
+
+
+@pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
 def test_bottleneck128_many_tiles_per_workgroup(dev, dtype):
     """More tiles than workgroup slots (12 x 50 = 600 > 512, so workgroups start while others are mid-tile), at the
     BASELINE map size of the 128-channel stage: both two-per-CU kernels equal the two cft_conv2d launches bit for bit."""
