@@ -106,14 +106,13 @@ def traffic_from_profile(args, n_launch, abytes):
             "source": f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
 
 
-def cpu_baseline(cfg, sd, height, width, batch, budget_s=30.0):
+def cpu_baseline(cfg, sd, rgb, ir, budget_s=30.0):
     """Reported baseline only: the oracle (a port of the reference forward to plain torch fp32; the reference tree
     itself is not on the GPU box) on the host cores, as BASELINE.md section 2 prescribes: batch min(B, 8), fused
     weights, and the BEST of a sweep over intra-op thread counts {8, 16, 32, 64, nproc} - more threads is not
     faster on a many-core host (round 1 ran 128 threads and lost 4x).  Bounded to ~budget_s of CPU work."""
     from oracle.cft_oracle import OracleModel
-    b = max(1, min(batch, 8))
-    rgb, ir = seeded_inputs(b, height, width, seed=0)
+    b, height, width = rgb.shape[0], rgb.shape[2], rgb.shape[3]     # the first min(B, 8) pairs of the timed batch itself
     om = OracleModel(cfg)
     ncpu = os.cpu_count() or 8
     default_threads = torch.get_num_threads()
@@ -133,7 +132,7 @@ def cpu_baseline(cfg, sd, height, width, batch, budget_s=30.0):
             om(sd, rgb[:1], ir[:1])                       # thread-pool warm-up at this width
             spent += time.perf_counter() - t0
             t0 = time.perf_counter()
-            om(sd, rgb, ir)
+            want = om(sd, rgb, ir)
             results[t] = time.perf_counter() - t0
             spent += results[t]
         best = min(results, key=results.get)
@@ -147,11 +146,84 @@ def cpu_baseline(cfg, sd, height, width, batch, budget_s=30.0):
     finally:
         torch.set_num_threads(default_threads)
     med = statistics.median(times)
-    return {"value": round(b / med, 3), "unit": "image-pairs/sec", "cores": best, "kind": "port",
+    cpu_baseline.best_threads = best
+    return want, {"value": round(b / med, 3), "unit": "image-pairs/sec", "cores": best, "kind": "port",
             "sample": f"oracle/cft_oracle.py fp32, same network and {height}x{width} inputs, batch {b}, median of "
                       f"{len(times)} forwards at the best thread count ({med:.2f} s each); sweep pairs/s by threads: "
-                      + ", ".join(f"{t}: {b / v:.2f}" for t, v in sorted(results.items()))
+                            + ", ".join(f"{t}: {b / v:.2f}" for t, v in sorted(results.items()))
                       + f"; os.cpu_count()={ncpu}; {spent:.0f} s of CPU work in total"}
+
+
+BOUNDS = {"f32": ("raw logits max-abs", 1e-3), "f16": ("sigmoid-space max-abs", 1e-2), "bf16": ("sigmoid-space max-abs", 2.5e-2)}
+REF_BF16_MAX_RATIO, REF_BF16_RMS_RATIO = 1.30, 1.10     # as tests/test_gpu_model.py: HIP bf16 error level vs the reference-style bf16 forward
+
+
+def _flat(raws):
+    return torch.cat([r.reshape(-1).float() for r in raws])
+
+
+def parity_at_bench_shape(dtype_name, got_raw, want_raw, ref16_raw=None, n_ref=0):
+    """The timed configuration checked against the oracle: ``got_raw`` are the head logits of the first
+    pairs of the replayed batch, ``want_raw`` the CPU oracle's for the same pairs (fp32).  16-bit runs are compared in sigmoid
+    space; bf16 additionally against the error level of the reference-style bf16 forward (oracle under CPU
+    autocast, pinned to the reference's own autocast outputs by tests/test_oracle_golden.py) on the first ``n_ref`` pairs."""
+    what, bound = BOUNDS[dtype_name]
+    g, w = _flat(got_raw), _flat(want_raw)
+    err = (g - w).abs().max().item() if dtype_name == "f32" else (g.sigmoid() - w.sigmoid()).abs().max().item()
+    out = {"pairs": int(got_raw[0].shape[0]), "check": what, "max_err": round(err, 6), "bound": bound,
+           "rms_logit_err_over_std": round(((g - w).pow(2).mean().sqrt() / w.std()).item(), 6), "ok": bool(err <= bound)}
+    if ref16_raw is not None and n_ref:
+        g2, w2, r2 = _flat([r[:n_ref] for r in got_raw]), _flat([r[:n_ref] for r in want_raw]), _flat(ref16_raw)
+        e_hip = (g2.sigmoid() - w2.sigmoid()).abs().max().item()
+        e_ref = (r2.sigmoid() - w2.sigmoid()).abs().max().item()
+        rms_hip = ((g2 - w2).pow(2).mean().sqrt() / w2.std()).item()
+        rms_ref = ((r2 - w2).pow(2).mean().sqrt() / w2.std()).item()
+        level_ok = e_hip <= REF_BF16_MAX_RATIO * e_ref + 1e-3 and rms_hip <= REF_BF16_RMS_RATIO * rms_ref + 2e-4
+        out["vs_reference_style_bf16"] = {"pairs": n_ref, "hip_max_err": round(e_hip, 6), "reference_bf16_max_err": round(e_ref, 6),
+                                          "hip_rms": round(rms_hip, 6), "reference_bf16_rms": round(rms_ref, 6), "ok": bool(level_ok)}
+        out["ok"] = bool(out["ok"] and level_ok)
+    return out
+
+
+class ClockSampler:
+    """Shader clock during a sustained leg, from the amdgpu sysfs DPM table (the line marked '*' of pp_dpm_sclk), sampled
+    at 10 Hz by a thread; ``mean_mhz`` is None where the file is not readable."""
+
+    def __init__(self):
+        import glob
+        import threading
+        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.samples, self.stop = [], threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        for p in self.paths:
+            try:
+                for ln in open(p).read().splitlines():
+                    if ln.rstrip().endswith("*"):
+                        return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+            except (OSError, ValueError, IndexError):
+                continue
+        return None
+
+    def _run(self):
+        while not self.stop.is_set():
+            v = self._read()
+            if v is not None:
+                self.samples.append(v)
+            self.stop.wait(0.1)
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop.set()
+        self.thread.join(2)
+
+    @property
+    def mean_mhz(self):
+        return round(sum(self.samples) / len(self.samples), 1) if self.samples else None
 
 
 def main():
@@ -168,6 +240,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run both backbones on one HIP stream")
+    ap.add_argument("--sustained-steps", type=int, default=500, help="extra >= 10 s leg at N = 1 (0 = skip)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed configuration")
     args = ap.parse_args()
 
     rank, world, local = D.init_from_env()
@@ -208,6 +282,23 @@ def main():
                                 sync=torch.cuda.synchronize)
     assert torch.isfinite(pred).all(), "non-finite detections"
     log(f"timed region: {elapsed:.3f} s for {args.steps} steps")
+    local_elapsed = getattr(D.timed_steps, "last_local_elapsed", elapsed)
+    n_par = 0 if args.no_parity else min(args.batch, 2 if args.no_cpu_baseline else 8)
+    with torch.no_grad():
+        raw_now = step_fn()[1]
+        torch.cuda.synchronize()
+    got_raw = [r[:n_par].float().cpu() for r in raw_now] if n_par else None
+    selfcheck = None
+    if world > 1:       # evidence that every rank took part and that the gathered rows are the ranks' own rows
+        selfcheck = D.gather_selfcheck(pred, gather.drain(), rank, world, elapsed_local=local_elapsed)
+    sustained = None
+    if world == 1 and args.sustained_steps > 0 and not args.no_graph:
+        with ClockSampler() as clk, torch.no_grad():
+            el_s = D.timed_steps(lambda: step_fn()[0], args.sustained_steps, 2, sync=torch.cuda.synchronize)
+        sustained = {"steps": args.sustained_steps, "seconds": round(el_s, 3), "value": round(args.batch * args.sustained_steps / el_s, 2),
+                     "unit": "image-pairs/sec", "ms_per_step": round(el_s / args.sustained_steps * 1e3, 3), "mean_sclk_mhz": clk.mean_mhz,
+                     "sclk_samples": len(clk.samples)}
+        log(f"sustained leg: {sustained}")
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -245,6 +336,7 @@ def main():
                                    f"{args.size}x{args.size}, {args.batch} pairs/GPU, BN folded, pre-NMS detections",
                        "pairs_per_gpu": args.batch, "image_size": args.size, "parallelism": f"batch-shard x{world}",
                        "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap},
+            "sustained": sustained, "multi_gpu_selfcheck": selfcheck,
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear family; incl. the dedicated Focus kernel and the fused 64- / 128-channel Bottleneck kernels: 2 + 27 launches of the cfg3 forward)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic_from_profile(args, n_launch, abytes), "launches_per_step": n_launch,
@@ -266,15 +358,47 @@ def main():
                 cap16.ir.copy_(ir)
                 el16 = D.timed_steps(lambda: cap16.replay_static()[0], args.steps, args.warmup, sync=torch.cuda.synchronize)
             assert torch.isfinite(cap16.pred).all()
+            got_raw16 = [r[:n_par].float().cpu() for r in cap16.raw] if n_par else None
             line["f16"] = {"value": round(args.batch * args.steps / el16, 2), "unit": "image-pairs/sec",
                            "ms_per_step": round(el16 / args.steps * 1e3, 3), "steps": args.steps,
                            "note": "same workload with compute dtype fp16 (the reference's own GPU precision, test.py:66-68)"}
             model.release_graphs()
             model.set_compute_dtype(dtype)
+        want_raw = None
+        sd_cpu = {k: v for k, v in model.cpu().state_dict().items()}      # fused (deployed) weights, fp32
+        rgb_c, ir_c = rgb[:max(n_par, 1)].cpu(), ir[:max(n_par, 1)].cpu()
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is reported at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(cfg, {k: v for k, v in model.cpu().state_dict().items()},
-                                                args.size, args.size, args.batch)
+            nb = max(1, min(args.batch, 8))
+            (_, want_raw), line["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, rgb[:nb].cpu(), ir[:nb].cpu())
+        ok = True
+        if n_par:
+            from oracle.cft_oracle import OracleModel
+            from oracle.lowp_oracle import AutocastOracle
+            threads = torch.get_num_threads()
+            torch.set_num_threads(getattr(cpu_baseline, "best_threads", min(16, os.cpu_count() or 8)))
+            try:
+                if want_raw is None or want_raw[0].shape[0] < n_par:
+                    _, want_raw = OracleModel(cfg)(sd_cpu, rgb_c, ir_c)
+                want_raw = [r[:n_par] for r in want_raw]
+                ref16, n_ref = None, 0
+                if args.dtype == "bf16":
+                    n_ref = min(2, n_par)
+                    t0 = time.perf_counter()
+                    _, ref16 = AutocastOracle(cfg)(sd_cpu, rgb_c[:n_ref], ir_c[:n_ref])
+                    log(f"reference-style bf16 forward of {n_ref} pairs on the host: {time.perf_counter() - t0:.1f} s")
+            finally:
+                torch.set_num_threads(threads)
+            line["parity_at_bench_shape"] = parity_at_bench_shape(args.dtype, got_raw, want_raw, ref16, n_ref)
+            ok = line["parity_at_bench_shape"]["ok"]
+            if "f16" in line and got_raw16 is not None:
+                line["f16"]["parity_at_bench_shape"] = parity_at_bench_shape("f16", got_raw16, want_raw)
+                ok = ok and line["f16"]["parity_at_bench_shape"]["ok"]
         print(json.dumps(line), flush=True)
+        if not ok:
+            log("PARITY FAILURE at the benchmarked shape - see parity_at_bench_shape in the line above")
+            if world > 1:
+                torch.distributed.destroy_process_group()
+            sys.exit(3)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -68,9 +68,8 @@ int cft_conv2d(const void* x, const void* w, const float* bias, const void* res,
  * x, y: NHWC channel slices (ldx/xoff, ldy/yoff) that must not overlap (the kernel reads a halo of x);
  * w1 [c][kpad1] and w2 [c][kpad2] in the cft_conv2d layout (BN folded).  Bit-identical to two cft_conv2d calls
  * (1x1 + SiLU, then 3x3 + SiLU + residual); the hidden tensor never reaches HBM.
- * w2_stages (c = 128; may be null): the same 3x3 weights as 36 stage images of 8 KiB written by cft_bottleneck_pack_w2.
- * With them the kernel streams the weights as contiguous 1-KiB requests through a 4-slot LDS ring (the faster form);
- * without them it fetches 16-KiB K tiles from w2 itself.  Same result either way.
+ * w2_stages (required for c = 128, ignored for c = 64): the same 3x3 weights as 36 stage images of 8 KiB written by
+ * cft_bottleneck_pack_w2; the kernel streams them as contiguous 1-KiB requests through a 4-slot LDS ring.
  */
 int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, int kpad1, const float* b1,
                    const void* w2, int kpad2, const void* w2_stages, const float* b2, void* y, int ldy, int yoff,
@@ -79,9 +78,6 @@ int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, int kpad1, 
 /* w2 [128][1152] (cft_conv2d layout of a 128 -> 128 3x3 conv) -> w2_stages: 36 x 8 KiB, stage u = k 32u .. 32u+31 of
  * every row in the order the kernel keeps it in LDS (c * kpad2 * 2 bytes, the size of w2). */
 int cft_bottleneck_pack_w2(const void* w2, int kpad2, int c, void* w2_stages, int dtype, void* stream);
-
-/* Timing probes (tools/bneck_probe.py): device buffer that the variant-932 Bottleneck kernel fills with cycle stamps. */
-int cft_set_debug_buffer(void* p);
 
 /* Tuning knob: force one tile configuration of cft_conv2d (0 = automatic, the default; see
  * csrc/conv_gemm.hip for the table).  Returns the previous value.  Not needed for normal use. */

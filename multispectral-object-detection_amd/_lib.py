@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ("runtime.hip", "conv_gemm.hip", "focus_conv.hip", "bottleneck.hip", "pointwise.hip", "attention.hip", "nms.hip", "train.hip")
 
 CFT_BF16, CFT_F32, CFT_F16 = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 
 _c = ctypes
@@ -30,7 +30,6 @@ SIGNATURES = {
     "cft_device_check": [],
     "cft_conv2d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_set_conv_variant": [_i],
-    "cft_set_debug_buffer": [_vp],
     "cft_bottleneck": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_bottleneck_pack_w2": [_vp, _i, _i, _vp, _i, _vp],
     "cft_focus_s2d": [_vp, _vp, _i, _i, _i, _i, _vp],
@@ -62,7 +61,25 @@ def build(verbose=False):
                                                        os.path.join(_HERE, "..", "include", "cft_hip.h")])
     if os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + srcs
+    # one object per source, compiled concurrently (only the stale ones), then one link
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, "cft_common.h")), os.path.getmtime(os.path.join(_HERE, "..", "include", "cft_hip.h")))
+    obj_dir = os.path.join(_HERE, "build")
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    jobs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time):
+            continue
+        cmd = ["hipcc"] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -19,8 +19,9 @@
 //                  Masked granules (image border, K tail, N tail) fetch from a zero page.
 //     GLDS = false global -> VGPR -> ds_write_b128 (register staging, loads issued one K step ahead)
 //   Double-buffered, one barrier per K step.  (Deeper vmcnt-counted rings, 32x32 MFMA with swapped
-//   operands + permlane epilogue and a register-double-buffered 8-wave variant were built and measured
-//   slower on MI355X - see profiles/r01_gemm_experiments.md - and are not part of the library.)
+//   operands + permlane epilogue, a register-double-buffered 8-wave variant and two hand-scheduled
+//   "8-phase" kernels with staggered wave groups were built and measured slower on MI355X - see
+//   profiles/r01_gemm_experiments.md, profiles/r02_gemm_experiments.md - and are not part of the library.)
 //   bf16: v_mfma_f32_16x16x32_bf16 (lane holds 8 consecutive k of one row = one granule);
 //   f32 : 4 x v_mfma_f32_16x16x4_f32 per granule (exact fp32 products, fp32 accumulate).
 //   Both operands use the same (lane-group, element) -> k assignment, so the reduction is a
@@ -385,404 +386,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
   conv_epilogue<typename Half16<T>::type, WM, WN>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
 }
 
-// ------------------------------------------------------------------------------------ 8-phase kernel
-// 256 x 256 x 64 tile, EIGHT waves (2 M-groups x 4), wave tile 128 x 64, for the wide MFMA-bound layers.  The K loop is
-// the multi-phase schedule of the CDNA4 GEMM playbook instead of "load tile / barrier / compute tile":
-//   * a K tile is computed in FOUR phases, one 64 x 32 quadrant of the wave tile each: (m0,n0) (m0,n1) (m1,n1) (m1,n0);
-//     a phase = [load segment: ds_read_b128 of the operand sub-tiles that change (8 x A and/or 4 x B), ONE staging unit
-//     (2 x global_load_lds per thread), counted s_waitcnt vmcnt] - s_barrier - [MFMA segment: 16 back-to-back MFMAs at
-//     raised priority] - s_barrier;
-//   * the two wave groups (waves 0-3 / 4-7, which share the four SIMDs pairwise) run ONE BARRIER apart, so that on every
-//     SIMD one wave is in its MFMA segment while its partner is in its load segment: the matrix pipe never waits for LDS;
-//   * staging runs ahead in half-tile units of 128 rows in the order the phases need them - A.m0, B.n0, B.n1, A.m1 of
-//     tile t+1, then A.m0 of tile t+2 ... - six units ahead of the compute phase, into the two LDS buffers: a unit is
-//     re-staged two to three phases after its slot's last fragment read.  vmcnt(8) (never 0) leaves four units = eight
-//     LDS-DMA requests per thread in flight ACROSS the barriers; a wait sits at the end of a load segment and covers
-//     exactly what the NEXT phase reads (a DMA is only ordered for other waves' ds_reads by the issuing wave's vmcnt
-//     followed by a barrier - and with the groups one barrier apart that barrier must be the one after this segment);
-//   * tiles beyond K are staged from the zero page, so the schedule (and every vmcnt count) is uniform to the end.
-// LDS image, swizzle, operand fragments, products, k order and the epilogue are those of conv_gemm_kernel: the results
-// are bit-identical to it (tests/test_gpu_ops.py runs it as variant 80).
-template <typename T, int ABLATE = 0>
-__global__ void __launch_bounds__(512) conv_gemm8_kernel(const ConvParams p) {
-  static_assert(sizeof(T) == 2, "16-bit operand types only");
-  constexpr int BM = 256, BN = 256, GE = 8, BK = 64, ES = 2;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;
-  unsigned char* sB = smem + 2 * A_BYTES;
-
-  const int nb = gridDim.x, bid = blockIdx.x;
-  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, slot = bid >> 3;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  const int tm = logical / p.tilesN, tn = logical - tm * p.tilesN;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;             // wm = wave group (waves w and w + 4 share a SIMD)
-  const int r0 = tid >> 3;                             // staging row within a 64-row pass
-  const int slot_s = tid & 7;
-  const int g = slot_s ^ (r0 & 7);                     // k-granule this thread fetches (source-side swizzle)
-
-  // ---- per-thread gather state: 4 pixel rows (r0 + 64 i), one k-granule column g ----
-  int a_off[4];
-  uint32_t a_mask[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + r0 + i * 64;
-    a_off[i] = 0;
-    a_mask[i] = 0;
-    if (m < p.M) {
-      const int t = fast_div(m, p.wo_mul, p.wo_sh);
-      const int wo = m - t * p.Wo;
-      const int b = fast_div(t, p.ho_mul, p.ho_sh);
-      const int ho = t - b * p.Ho;
-      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-      a_off[i] = ((b * p.H + hi0) * p.W + wi0) * p.ldx + p.xoff;
-      uint32_t wbits = 0, mk = 0;
-      for (int kw = 0; kw < p.KS; ++kw) wbits |= ((unsigned)(wi0 + kw) < (unsigned)p.W ? 1u : 0u) << kw;
-      for (int kh = 0; kh < p.KS; ++kh)
-        if ((unsigned)(hi0 + kh) < (unsigned)p.H) mk |= wbits << (kh * p.KS);
-      a_mask[i] = mk;
-    }
-  }
-  // weight rows this thread stages: unit n0 -> rows (h>>5)*64 + (h&31), unit n1 -> + 32, h = r0 + 64 j
-  long b_row_off[2];
-  bool b_ok[2][2];
-  int b_lds[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int h = r0 + 64 * j;
-    const int nrow = (h >> 5) * 64 + (h & 31);
-    b_row_off[j] = (long)(n0 + nrow) * p.Kpad;
-    b_ok[j][0] = n0 + nrow < p.N;
-    b_ok[j][1] = n0 + nrow + 32 < p.N;
-    b_lds[j] = (((wave * 8 + 64 * j) >> 5) * 64 + ((wave * 8) & 31)) * 128;   // wave-uniform LDS row base of this pass
-  }
-  int ci = g * GE, kh = 0, kw = 0, tap = 0;
-  while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }
-  int koff = (kh * p.W + kw) * p.ldx + ci;
-  const int tap_step = p.ldx - p.Cin;
-  const int row_step = (p.W - p.KS) * p.ldx;
-  const bool wide_cin = p.Cin >= BK;
-  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(cft_zero_page);
-  int ts = 0;                     // K tile being staged
-  int kglob = g * GE;             // its k position for this thread
-
-// stage one unit of tile ts: 0 = A rows {r0, r0+128} (m0), 3 = A rows {r0+64, r0+192} (m1), 1 / 2 = B units n0 / n1
-#define CFT8_STAGE_A(i_)                                                                                  \
-  {                                                                                                       \
-    const bool v_ = (kglob < p.K) && ((a_mask[i_] >> tap) & 1u);                                          \
-    const unsigned char* src_ = v_ ? p.x + (long)(a_off[i_] + koff) * ES : zero_page;                     \
-    if constexpr (!(ABLATE & 1))                                                                          \
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(sA + (ts & 1) * A_BYTES + (i_) * 8192 + wave * 1024), 16, 0, 0); \
-  }
-#define CFT8_STAGE_B(j_, nh_)                                                                             \
-  {                                                                                                       \
-    const bool v_ = b_ok[j_][nh_] && (kglob < p.Kpad);                                                    \
-    const unsigned char* src_ = v_ ? p.w + (b_row_off[j_] + (long)(nh_) * 32 * p.Kpad + kglob) * ES : zero_page; \
-    if constexpr (!(ABLATE & 1))                                                                          \
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(sB + (ts & 1) * B_BYTES + b_lds[j_] + (nh_) * 4096), 16, 0, 0); \
-  }
-#define CFT8_ADVANCE()                                                                                    \
-  {                                                                                                       \
-    ++ts; kglob += BK; ci += BK; koff += BK;                                                              \
-    if (wide_cin) {                                                                                       \
-      const bool wrap = ci >= p.Cin;                                                                      \
-      ci -= wrap ? p.Cin : 0; koff += wrap ? tap_step : 0; tap += wrap ? 1 : 0; kw += wrap ? 1 : 0;       \
-      const bool roww = kw == p.KS;                                                                       \
-      kw = roww ? 0 : kw; koff += roww ? row_step : 0;                                                    \
-    } else {                                                                                              \
-      while (ci >= p.Cin) { ci -= p.Cin; koff += tap_step; ++tap; if (++kw == p.KS) { kw = 0; koff += row_step; } } \
-    }                                                                                                     \
-  }
-#define CFT8_UNIT_AM0() { CFT8_STAGE_A(0) CFT8_STAGE_A(2) }
-#define CFT8_UNIT_BN0() { CFT8_STAGE_B(0, 0) CFT8_STAGE_B(1, 0) }
-#define CFT8_UNIT_BN1() { CFT8_STAGE_B(0, 1) CFT8_STAGE_B(1, 1) }
-#define CFT8_UNIT_AM1() { CFT8_STAGE_A(1) CFT8_STAGE_A(3) CFT8_ADVANCE() }
-#define CFT8_BARRIER() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-#define CFT8_WAIT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-
-  f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  // fragment read bases (bytes inside one buffer): row*128 + (k-group ^ (row & 7)) * 16 for the first 32-wide k chunk;
-  // the second chunk (k-group + 4) flips bit 6 of the byte offset
-  const int lrow = lane & 15, lgrp = lane >> 4;
-  const int fa0 = (wm * 128 + lrow) * 128 + ((lgrp ^ (lrow & 7)) << 4);
-  const int fb0 = (wn * 64 + lrow) * 128 + ((lgrp ^ (lrow & 7)) << 4);
-  gran_t af[4][2], bf0[2][2], bf1[2][2];
-#define CFT8_READ_A(mh_, cb_)                                                                             \
-  _Pragma("unroll") for (int ti = 0; ti < 4; ++ti) {                                                      \
-    af[ti][0] = *reinterpret_cast<const gran_t*>(sA + (cb_) * A_BYTES + ((mh_) * 64 + ti * 16) * 128 + fa0);        \
-    af[ti][1] = *reinterpret_cast<const gran_t*>(sA + (cb_) * A_BYTES + ((mh_) * 64 + ti * 16) * 128 + (fa0 ^ 64)); \
-  }
-#define CFT8_READ_B(dst_, nh_, cb_)                                                                       \
-  _Pragma("unroll") for (int tj = 0; tj < 2; ++tj) {                                                      \
-    dst_[tj][0] = *reinterpret_cast<const gran_t*>(sB + (cb_) * B_BYTES + ((nh_) * 32 + tj * 16) * 128 + fb0);        \
-    dst_[tj][1] = *reinterpret_cast<const gran_t*>(sB + (cb_) * B_BYTES + ((nh_) * 32 + tj * 16) * 128 + (fb0 ^ 64)); \
-  }
-#define CFT8_MMA(mh_, nh_, bsrc_)                                                                         \
-  {                                                                                                       \
-    __builtin_amdgcn_s_setprio(1);                                                                        \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
-      _Pragma("unroll") for (int ti = 0; ti < 4; ++ti)                                                    \
-        _Pragma("unroll") for (int tj = 0; tj < 2; ++tj) {                                                \
-          if constexpr (ABLATE & 2) { asm volatile("" ::"v"(af[ti][ks]), "v"(bsrc_[tj][ks])); }           \
-          else acc[(mh_) * 4 + ti][(nh_) * 2 + tj] = mma_granule<T>(af[ti][ks], bsrc_[tj][ks], acc[(mh_) * 4 + ti][(nh_) * 2 + tj]); \
-        }                                                                                                 \
-    __builtin_amdgcn_s_setprio(0);                                                                        \
-  }
-
-  // ---- prologue: units 0..5 = all of tile 0, A.m0 and B.n0 of tile 1; tile 0's first two units must have landed
-  CFT8_UNIT_AM0() CFT8_UNIT_BN0() CFT8_UNIT_BN1() CFT8_UNIT_AM1()
-  CFT8_UNIT_AM0() CFT8_UNIT_BN0()
-  CFT8_WAIT8()
-  CFT8_BARRIER()
-  if (wm == 1) CFT8_BARRIER()          // group 1 runs one barrier behind group 0
-
-  const int nk = p.Kpad / BK;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cb = kt & 1;
-    // phase 1: quadrant (m0, n0)
-    CFT8_READ_A(0, cb)
-    CFT8_READ_B(bf0, 0, cb)
-    CFT8_UNIT_BN1()
-    CFT8_WAIT8()
-    CFT8_BARRIER()
-    CFT8_MMA(0, 0, bf0)
-    CFT8_BARRIER()
-    // phase 2: quadrant (m0, n1)
-    CFT8_READ_B(bf1, 1, cb)
-    CFT8_UNIT_AM1()
-    CFT8_WAIT8()
-    CFT8_BARRIER()
-    CFT8_MMA(0, 1, bf1)
-    CFT8_BARRIER()
-    // phase 3: quadrant (m1, n1)
-    CFT8_READ_A(1, cb)
-    CFT8_UNIT_AM0()
-    CFT8_BARRIER()
-    CFT8_MMA(1, 1, bf1)
-    CFT8_BARRIER()
-    // phase 4: quadrant (m1, n0); the wait covers A.m0 / B.n0 of the next tile
-    CFT8_UNIT_BN0()
-    CFT8_WAIT8()
-    CFT8_BARRIER()
-    CFT8_MMA(1, 0, bf0)
-    CFT8_BARRIER()
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-page units staged past K still land in LDS
-  if (wm == 0) CFT8_BARRIER()          // group 0 catches up with group 1's extra barrier
-  CFT8_BARRIER()                        // no wave still reads (or DMA-writes) the staging buffers the strips alias
-#undef CFT8_STAGE_A
-#undef CFT8_STAGE_B
-#undef CFT8_ADVANCE
-#undef CFT8_UNIT_AM0
-#undef CFT8_UNIT_BN0
-#undef CFT8_UNIT_BN1
-#undef CFT8_UNIT_AM1
-#undef CFT8_BARRIER
-#undef CFT8_WAIT8
-#undef CFT8_READ_A
-#undef CFT8_READ_B
-#undef CFT8_MMA
-
-  if constexpr (ABLATE & 16) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-    return;
-  }
-  float bias_v[4];
-  conv_load_bias<64>(p, n0, wn, lane, bias_v);
-  conv_epilogue<T, 128, 64>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
-}
-
-// 256 x 128 x 64 sibling for the 128-channel layers (N <= 128): eight waves as 2 M-groups x 4, wave tile 128 x 32, the same
-// staggered two-group schedule with TWO phases per K tile (rows m0 / m1 of the wave tile; the four B fragments stay in
-// registers for both) and THREE LDS buffers (144 KiB): all six LDS-DMA requests of tile t+2 are issued while tile t is
-// computed (three per phase, in the order the phases need them: A.m0 A.m0 B | B A.m1 A.m1), so a tile has two full K
-// tiles of lead and vmcnt(9) / vmcnt(8) leave 8-9 requests per thread in flight across the barriers.
-template <typename T, int ABLATE = 0>
-__global__ void __launch_bounds__(512) conv_gemm8n_kernel(const ConvParams p) {
-  static_assert(sizeof(T) == 2, "16-bit operand types only");
-  constexpr int BM = 256, BN = 128, GE = 8, BK = 64, ES = 2;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;
-  unsigned char* sB = smem + 3 * A_BYTES;
-
-  const int nb = gridDim.x, bid = blockIdx.x;
-  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, slot = bid >> 3;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  const int tm = logical / p.tilesN, tn = logical - tm * p.tilesN;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int r0 = tid >> 3;
-  const int slot_s = tid & 7;
-  const int g = slot_s ^ (r0 & 7);
-
-  int a_off[4];
-  uint32_t a_mask[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + r0 + i * 64;
-    a_off[i] = 0;
-    a_mask[i] = 0;
-    if (m < p.M) {
-      const int t = fast_div(m, p.wo_mul, p.wo_sh);
-      const int wo = m - t * p.Wo;
-      const int b = fast_div(t, p.ho_mul, p.ho_sh);
-      const int ho = t - b * p.Ho;
-      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-      a_off[i] = ((b * p.H + hi0) * p.W + wi0) * p.ldx + p.xoff;
-      uint32_t wbits = 0, mk = 0;
-      for (int kw = 0; kw < p.KS; ++kw) wbits |= ((unsigned)(wi0 + kw) < (unsigned)p.W ? 1u : 0u) << kw;
-      for (int kh = 0; kh < p.KS; ++kh)
-        if ((unsigned)(hi0 + kh) < (unsigned)p.H) mk |= wbits << (kh * p.KS);
-      a_mask[i] = mk;
-    }
-  }
-  long b_row_off[2];
-  bool b_ok[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    b_row_off[j] = (long)(n0 + r0 + 64 * j) * p.Kpad;
-    b_ok[j] = n0 + r0 + 64 * j < p.N;
-  }
-  int ci = g * GE, kh = 0, kw = 0, tap = 0;
-  while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kw == p.KS) { kw = 0; ++kh; } }
-  int koff = (kh * p.W + kw) * p.ldx + ci;
-  const int tap_step = p.ldx - p.Cin;
-  const int row_step = (p.W - p.KS) * p.ldx;
-  const bool wide_cin = p.Cin >= BK;
-  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(cft_zero_page);
-  int sb = 0;                     // LDS buffer of the K tile being staged (tile index mod 3)
-  int kglob = g * GE;
-
-#define CFT8_STAGE_A(i_)                                                                                  \
-  {                                                                                                       \
-    const bool v_ = (kglob < p.K) && ((a_mask[i_] >> tap) & 1u);                                          \
-    const unsigned char* src_ = v_ ? p.x + (long)(a_off[i_] + koff) * ES : zero_page;                     \
-    if constexpr (!(ABLATE & 1))                                                                          \
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(sA + sb * A_BYTES + (i_) * 8192 + wave * 1024), 16, 0, 0); \
-  }
-#define CFT8_STAGE_B(j_)                                                                                  \
-  {                                                                                                       \
-    const bool v_ = b_ok[j_] && (kglob < p.Kpad);                                                         \
-    const unsigned char* src_ = v_ ? p.w + (b_row_off[j_] + kglob) * ES : zero_page;                      \
-    if constexpr (!(ABLATE & 1))                                                                          \
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(sB + sb * B_BYTES + (j_) * 8192 + wave * 1024), 16, 0, 0); \
-  }
-#define CFT8_ADVANCE()                                                                                    \
-  {                                                                                                       \
-    sb = sb == 2 ? 0 : sb + 1; kglob += BK; ci += BK; koff += BK;                                         \
-    if (wide_cin) {                                                                                       \
-      const bool wrap = ci >= p.Cin;                                                                      \
-      ci -= wrap ? p.Cin : 0; koff += wrap ? tap_step : 0; tap += wrap ? 1 : 0; kw += wrap ? 1 : 0;       \
-      const bool roww = kw == p.KS;                                                                       \
-      kw = roww ? 0 : kw; koff += roww ? row_step : 0;                                                    \
-    } else {                                                                                              \
-      while (ci >= p.Cin) { ci -= p.Cin; koff += tap_step; ++tap; if (++kw == p.KS) { kw = 0; koff += row_step; } } \
-    }                                                                                                     \
-  }
-#define CFT8_TRIPLE_1() { CFT8_STAGE_A(0) CFT8_STAGE_A(2) CFT8_STAGE_B(0) }
-#define CFT8_TRIPLE_2() { CFT8_STAGE_B(1) CFT8_STAGE_A(1) CFT8_STAGE_A(3) CFT8_ADVANCE() }
-#define CFT8_BARRIER() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-
-  f32x4_t acc[8][2];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int lrow = lane & 15, lgrp = lane >> 4;
-  const int fa0 = (wm * 128 + lrow) * 128 + ((lgrp ^ (lrow & 7)) << 4);
-  const int fb0 = (wn * 32 + lrow) * 128 + ((lgrp ^ (lrow & 7)) << 4);
-  gran_t af[4][2], bf[2][2];
-#define CFT8_READ_A(mh_, cb_)                                                                             \
-  _Pragma("unroll") for (int ti = 0; ti < 4; ++ti) {                                                      \
-    af[ti][0] = *reinterpret_cast<const gran_t*>(sA + (cb_) * A_BYTES + ((mh_) * 64 + ti * 16) * 128 + fa0);        \
-    af[ti][1] = *reinterpret_cast<const gran_t*>(sA + (cb_) * A_BYTES + ((mh_) * 64 + ti * 16) * 128 + (fa0 ^ 64)); \
-  }
-#define CFT8_READ_B(cb_)                                                                                  \
-  _Pragma("unroll") for (int tj = 0; tj < 2; ++tj) {                                                      \
-    bf[tj][0] = *reinterpret_cast<const gran_t*>(sB + (cb_) * B_BYTES + (tj * 16) * 128 + fb0);           \
-    bf[tj][1] = *reinterpret_cast<const gran_t*>(sB + (cb_) * B_BYTES + (tj * 16) * 128 + (fb0 ^ 64));    \
-  }
-#define CFT8_MMA(mh_)                                                                                     \
-  {                                                                                                       \
-    __builtin_amdgcn_s_setprio(1);                                                                        \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
-      _Pragma("unroll") for (int ti = 0; ti < 4; ++ti)                                                    \
-        _Pragma("unroll") for (int tj = 0; tj < 2; ++tj) {                                                \
-          if constexpr (ABLATE & 2) { asm volatile("" ::"v"(af[ti][ks]), "v"(bf[tj][ks])); }              \
-          else acc[(mh_) * 4 + ti][tj] = mma_granule<T>(af[ti][ks], bf[tj][ks], acc[(mh_) * 4 + ti][tj]); \
-        }                                                                                                 \
-    __builtin_amdgcn_s_setprio(0);                                                                        \
-  }
-
-  // ---- prologue: tiles 0 and 1 completely (12 requests); the first four of tile 0 must have landed
-  CFT8_TRIPLE_1() CFT8_TRIPLE_2()
-  CFT8_TRIPLE_1() CFT8_TRIPLE_2()
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  CFT8_BARRIER()
-  if (wm == 1) CFT8_BARRIER()
-
-  const int nk = p.Kpad / BK;
-  int cb = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // phase 1: rows m0 of the wave tile; stages the first half of tile kt + 2; the wait covers A.m1 of this tile
-    CFT8_READ_A(0, cb)
-    CFT8_READ_B(cb)
-    CFT8_TRIPLE_1()
-    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    CFT8_BARRIER()
-    CFT8_MMA(0)
-    CFT8_BARRIER()
-    // phase 2: rows m1; stages the second half of tile kt + 2; the wait covers A.m0 and B of tile kt + 1
-    CFT8_READ_A(1, cb)
-    CFT8_TRIPLE_2()
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    CFT8_BARRIER()
-    CFT8_MMA(1)
-    CFT8_BARRIER()
-    cb = cb == 2 ? 0 : cb + 1;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (wm == 0) CFT8_BARRIER()
-  CFT8_BARRIER()
-#undef CFT8_STAGE_A
-#undef CFT8_STAGE_B
-#undef CFT8_ADVANCE
-#undef CFT8_TRIPLE_1
-#undef CFT8_TRIPLE_2
-#undef CFT8_BARRIER
-#undef CFT8_READ_A
-#undef CFT8_READ_B
-#undef CFT8_MMA
-
-  if constexpr (ABLATE & 16) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
-    return;
-  }
-  float bias_v[2];
-  conv_load_bias<32>(p, n0, wn, lane, bias_v);
-  conv_epilogue<T, 128, 32>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
-}
-
 // ------------------------------------------------------------------------------------ host
 // (mul, sh) with floor(n / d) == umulhi(n, mul) >> sh for all 0 <= n < 2^31 (d >= 2); mul = 0 encodes d == 1.
 static void set_magic(int d, uint32_t& mul, uint32_t& sh) {
@@ -795,7 +398,7 @@ static void set_magic(int d, uint32_t& mul, uint32_t& sh) {
 }
 
 // Tile variants.  0 = automatic choice; the others force one configuration (tuning / A-B tests).
-int g_conv_variant = 0;   // also read by bottleneck.hip (ablation probes 9xx)
+int g_conv_variant = 0;   // also read by bottleneck.hip in probe builds (-DCFT_PROBES)
 extern "C" int cft_set_conv_variant(int v) {
   const int old = g_conv_variant;
   g_conv_variant = v;
@@ -813,58 +416,9 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
   return cft_check_launch("conv_gemm_kernel");
 }
 
-template <typename T, int ABLATE = 0>
-static int launch_conv8(const ConvParams& p, hipStream_t stream) {
-  if constexpr (sizeof(T) == 2) {
-    constexpr int smem_bytes = 2 * (256 + 256) * 128;
-    cft_allow_lds<&conv_gemm8_kernel<T, ABLATE>>(smem_bytes);
-    ConvParams q = p;
-    const int tilesM = (p.M + 255) / 256;
-    q.tilesN = (p.N + 255) / 256;
-    hipLaunchKernelGGL((conv_gemm8_kernel<T, ABLATE>), dim3(tilesM * q.tilesN), dim3(512), smem_bytes, stream, q);
-    return cft_check_launch("conv_gemm8_kernel");
-  } else {
-    return launch_conv<T, 256, 256, 4, 4, true>(p, stream);   // fp32: the 16-wave kernel
-  }
-}
-
-template <typename T, int ABLATE = 0>
-static int launch_conv8n(const ConvParams& p, hipStream_t stream) {
-  if constexpr (sizeof(T) == 2) {
-    constexpr int smem_bytes = 3 * (256 + 128) * 128;
-    cft_allow_lds<&conv_gemm8n_kernel<T, ABLATE>>(smem_bytes);
-    ConvParams q = p;
-    const int tilesM = (p.M + 255) / 256;
-    q.tilesN = (p.N + 127) / 128;
-    hipLaunchKernelGGL((conv_gemm8n_kernel<T, ABLATE>), dim3(tilesM * q.tilesN), dim3(512), smem_bytes, stream, q);
-    return cft_check_launch("conv_gemm8n_kernel");
-  } else {
-    return launch_conv<T, 192, 128, 2, 4, true>(p, stream);
-  }
-}
-
-// The staggered-group kernels are bit-identical to the lock-step ones but measured SLOWER on MI355X when both operands
-// stream through the LDS-DMA path (profiles/r02_gemm_experiments.md: their MFMA-only loop runs at 1.6 PFLOP/s, but the
-// L2 -> LDS request stream, 64 KiB per K tile per CU, needs 1.18 us per tile against 1.01 us of MFMA work and does
-// not overlap well across the 8 barriers per tile).  They stay selectable (variants 80 / 81, or CFT_AUTO8=1 in the
-// environment to put them into the automatic choice for A/B runs); the default choice is unchanged.
-static bool auto8_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CFT_AUTO8"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
-
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   switch (g_conv_variant) {
-    case 80: return launch_conv8<T>(p, stream);               // 8-phase 256x256 (two staggered wave groups)
-    case 81: return launch_conv8n<T>(p, stream);              // 256x128 sibling (3 LDS buffers)
-    case 181: return launch_conv8n<T, 1>(p, stream);
-    case 281: return launch_conv8n<T, 2>(p, stream);
-    case 1681: return launch_conv8n<T, 16>(p, stream);
-    case 180: return launch_conv8<T, 1>(p, stream);
-    case 280: return launch_conv8<T, 2>(p, stream);
-    case 1680: return launch_conv8<T, 16>(p, stream);   // forced configurations (tools/gemm_bench.py, tests); 1xx/2xx/3xx = ablations of xx
     case 1: return launch_conv<T, 128, 128, 2, 2, false>(p, stream);   // register-staged baseline
     case 2: return launch_conv<T, 128, 128, 2, 2, true>(p, stream);
     case 4: return launch_conv<T, 128, 64, 2, 2, true>(p, stream);
@@ -885,6 +439,7 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
     case 73: return launch_conv<T, 256, 80, 4, 1, true>(p, stream);
     case 74: return launch_conv<T, 256, 80, 8, 1, true>(p, stream);
     case 75: return launch_conv<T, 128, 80, 4, 1, true>(p, stream);
+#ifdef CFT_PROBES   // timing probes / A-B variants (tools/build_probes.sh): results of 1xx/2xx/3xx/16xx are wrong by construction
     case 3223: return launch_conv<T, 128, 128, 2, 4, true, 32>(p, stream);   // 32xx: bias loaded at the epilogue (round-1 placement)
     case 3251: return launch_conv<T, 192, 128, 2, 4, true, 32>(p, stream);
     case 3227: return launch_conv<T, 256, 256, 4, 4, true, 32>(p, stream);
@@ -893,6 +448,7 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
     case 127: return launch_conv<T, 256, 256, 4, 4, true, 1>(p, stream);
     case 227: return launch_conv<T, 256, 256, 4, 4, true, 2>(p, stream);
     case 327: return launch_conv<T, 256, 256, 4, 4, true, 3>(p, stream);
+#endif
     default: break;
   }
   // Automatic choice (measured on MI355X with tools/gemm_bench.py, yolov5l+CFTx3 layer shapes, bf16):
@@ -901,7 +457,6 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   //  * HBM-bound layers (1x1, K <= 256) run best on 8-wave 128x128 / 256x64 tiles (4.3-4.8 TB/s);
   //  * a tile configuration is only used if it yields at least one workgroup per CU.
   auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-  const bool use8 = sizeof(T) == 2 && (g_conv_variant == 8000 || (g_conv_variant == 0 && auto8_enabled()));
   const long kCUs = 192;   // accept a configuration once it yields >= 0.75 workgroups per CU (256 CUs)
   if (p.N <= 64) {
     if (tiles(256, 64) >= kCUs) return launch_conv<T, 256, 64, 4, 2, true>(p, stream);
@@ -921,7 +476,6 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   if (p.N <= 128) {
     // 192x128 with 8 waves is the largest 128-wide tile of which TWO workgroups fit a CU (80 KiB LDS each): the
     // store/residual burst of one workgroup's epilogue overlaps the other's K loop (+5..8 % over 512x128x16w).
-    if (use8 && p.Kpad >= 512 && tiles(256, 128) >= 2 * kCUs) return launch_conv8n<T>(p, stream);
     if (tiles(192, 128) >= 2 * kCUs) return launch_conv<T, 192, 128, 2, 4, true>(p, stream);
     if (tiles(128, 128) >= 2 * kCUs) return launch_conv<T, 128, 128, 2, 4, true>(p, stream);
     return launch_conv<T, 64, 128, 2, 4, true>(p, stream);          // few tiles: 3 workgroups of 8 waves per CU
@@ -929,7 +483,6 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   // wide layers: prefer 256-wide tiles unless the N tail would waste much more than 128-wide tiles do
   const long pad256 = (long)((p.N + 255) / 256) * 256, pad128 = (long)((p.N + 127) / 128) * 128;
   const bool wide_ok = pad256 * 100 <= pad128 * 115;
-  if (use8 && wide_ok && p.Kpad >= 512 && tiles(256, 256) >= kCUs) return launch_conv8<T>(p, stream);
   if (wide_ok && p.Kpad >= 256 && tiles(256, 256) >= kCUs) return launch_conv<T, 256, 256, 4, 4, true>(p, stream);
   if (wide_ok && tiles(128, 256) >= kCUs) return launch_conv<T, 128, 256, 4, 4, true>(p, stream);   // e.g. CFT fc2 at M = 8192
   if (tiles(192, 128) >= 2 * kCUs) return launch_conv<T, 192, 128, 2, 4, true>(p, stream);

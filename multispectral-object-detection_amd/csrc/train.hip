@@ -17,8 +17,12 @@ __global__ void __launch_bounds__(1024) bn_partial_kernel(const float* __restric
   const long m0 = (long)blockIdx.x * rows_per_blk;
   const long m1 = (m0 + rows_per_blk < M) ? m0 + rows_per_blk : M;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
+  // sums of (x - pivot): the pivot (row 0 of the tensor, the same for every slab) removes the cancellation of
+  // E[x^2] - mean^2 for channels with |mean| >> std
+  const float4 pv = *reinterpret_cast<const float4*>(x + xoff + g * 4L);
   for (long m = m0 + r; m < m1; m += rpp) {
-    const float4 v = *reinterpret_cast<const float4*>(x + m * ldx + xoff + g * 4L);
+    float4 v = *reinterpret_cast<const float4*>(x + m * ldx + xoff + g * 4L);
+    v.x -= pv.x; v.y -= pv.y; v.z -= pv.z; v.w -= pv.w;
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
   }
@@ -37,7 +41,7 @@ __global__ void __launch_bounds__(1024) bn_partial_kernel(const float* __restric
   }
 }
 
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, int Cp, long M,
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ x, long xoff, const float* __restrict__ part, int nblk, int C, int Cp, long M,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           float momentum, float eps, float* __restrict__ scale_shift) {
@@ -49,9 +53,10 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
     s += (double)part[(long)k * 2 * Cp + c];
     q += (double)part[(long)k * 2 * Cp + Cp + c];
   }
-  const double mean = s / (double)M;
-  double var = q / (double)M - mean * mean;
+  const double dm = s / (double)M;                  // mean of (x - pivot)
+  double var = q / (double)M - dm * dm;
   var = var < 0.0 ? 0.0 : var;
+  const double mean = (double)x[xoff + c] + dm;
   const float sc = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
   scale_shift[c] = sc;
   scale_shift[Cp + c] = beta[c] - (float)mean * sc;
@@ -122,7 +127,7 @@ extern "C" int cft_batchnorm_train(const float* x, int ldx, int xoff, long M, in
   rpp = rpp < 1 ? 1 : (rpp > 16 ? 16 : rpp);
   CFT_REQUIRE(G <= 1024, "cft_batchnorm_train: too many channels for one workgroup");
   hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)nblk), dim3(G * rpp), (size_t)2 * rpp * G * 16, s, x, (long)ldx, (long)xoff, M, G, rpp, 4096L, part);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 255) / 256), dim3(256), 0, s, part, (int)nblk, C, Cp, M, gamma, beta, running_mean, running_var,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 255) / 256), dim3(256), 0, s, x, (long)xoff, part, (int)nblk, C, Cp, M, gamma, beta, running_mean, running_var,
                      momentum, eps, scale_shift);
   const int gpp = Cp / ge;
   long g = (M * gpp + 255) / 256;

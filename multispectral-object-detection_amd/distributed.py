@@ -145,6 +145,7 @@ def timed_steps(step_fn, steps, warmup, world=1, gather=None, sync=None, group=N
     if multi:
         dist.barrier(group=group)
     elapsed = time.perf_counter() - t0
+    timed_steps.last_local_elapsed = elapsed          # this rank's own clock (the self-check gathers one per rank)
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gather.out[0].device if gather is not None else "cpu")
         if t.device.type == "cpu" and dist.get_backend(group) == "nccl":
@@ -184,3 +185,46 @@ class OverlappedGather:
                 self.pending[i].wait()
                 self.pending[i] = None
         return self.out[(self.tick - 1) & 1] if self.tick else None
+
+
+def gather_selfcheck(local, gathered, rank, world, elapsed_local=None, group=None, gather_probe_steps=3):
+    """Evidence for an N > 1 bench line, computed from collectives so that a stub or a silently
+    single-rank run cannot produce it: ``n_ranks_seen`` = ranks that contributed to an all-gather of their rank ids;
+    ``rows_ok`` = rank 0's gathered rows [B r, B (r+1)) equal rank r's local tensor (compared through a float64
+    sum, a float64 sum of squares and 16 strided samples that every rank all-gathers); ``per_rank_elapsed_s`` = every
+    rank's own timed-region seconds; ``gather_ms`` = median wall time of ``gather_probe_steps`` synchronous gathers.
+    Returns a dict on every rank (identical content)."""
+    import statistics
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    if not multi:
+        return {"n_ranks_seen": 1, "rows_ok": True, "per_rank_elapsed_s": [elapsed_local], "gather_ms": 0.0}
+    dev = local.device
+    ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(ids, torch.tensor([rank], dtype=torch.int64, device=dev), group=group)
+    seen = sorted({int(t.item()) for t in ids})
+
+    def fingerprint(t):
+        f = t.reshape(-1).to(torch.float64)
+        idx = torch.linspace(0, f.numel() - 1, 16, device=f.device).long()
+        return torch.cat([f.sum().view(1), (f * f).sum().view(1), f[idx]])
+
+    mine = fingerprint(local)
+    fps = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(fps, mine, group=group)
+    B = local.shape[0]
+    rows_ok = all(torch.equal(fingerprint(gathered[r * B:(r + 1) * B]), fps[r]) for r in range(world))
+    el = torch.tensor([elapsed_local if elapsed_local is not None else 0.0], dtype=torch.float64, device=dev)
+    els = [torch.zeros_like(el) for _ in range(world)]
+    dist.all_gather(els, el, group=group)
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    times = []
+    out = torch.empty((world * B,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+    for _ in range(gather_probe_steps):
+        dist.barrier(group=group)
+        sync()
+        t0 = time.perf_counter()
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        sync()
+        times.append((time.perf_counter() - t0) * 1e3)
+    return {"n_ranks_seen": len(seen), "rows_ok": bool(rows_ok), "per_rank_elapsed_s": [round(float(t.item()), 6) for t in els],
+            "gather_ms": round(statistics.median(times), 3)}

@@ -180,6 +180,7 @@ class Model(nn.Module):
             self._initialize_biases()
         self._graphs = {}
         self.compute_dtype = torch.bfloat16
+        self.set_compute_dtype(torch.bfloat16)   # the Focus modules (where the network's precision is set) mirror it
         self.overlap_streams = True      # run the RGB and the IR backbone on two HIP streams
         self.eval()
 
@@ -191,6 +192,7 @@ class Model(nn.Module):
             p = next(self.parameters(), None)       # (checkpoints are saved .half(), train.py:852; attempt_load then .float()s)
             self.__dict__["compute_dtype"] = p.dtype if p is not None and p.dtype in ops.COMPUTE_DTYPES else torch.float32
         self.__dict__.setdefault("overlap_streams", True)
+        self.set_compute_dtype(self.compute_dtype)   # Focus.compute_dtype always mirrors Model.compute_dtype
 
     # ---- weight-change tracking: a captured graph replays the packed buffers of capture time -------
     def invalidate_packed(self):
@@ -238,7 +240,7 @@ class Model(nn.Module):
             raise ValueError(f"image height and width must be multiples of the largest stride ({smax}); got "
                              f"{x.shape[2]}x{x.shape[3]} (the reference letterboxes to such sizes, utils/datasets.py:1698-1728)")
         key = (tuple(x.shape), self.compute_dtype, x.dtype)
-        g = None if self.training else self._graphs.get(key)
+        g = None if (self.training or profile) else self._graphs.get(key)     # profile: per-layer events need eager launches
         if g is not None:
             if g.weights_key == self.weights_key():
                 return g.replay(x, x2)
@@ -359,15 +361,35 @@ class Model(nn.Module):
         two parallel branches of the graph).  Every tensor that crosses lanes is a saved layer output
         and stays referenced in ``y`` until the walk ends, so the caching allocator cannot recycle it
         under a kernel of the other stream."""
-        lanes = self.stream_lanes() if (self.overlap_streams and x.is_cuda) else None
+        lanes = self.stream_lanes() if (self.overlap_streams and x.is_cuda and not profile) else None
         cbufs = {} if (x.is_cuda and self.__dict__.get("plan_concats", True)) else None   # planned concat buffers of this walk
         if lanes is None or 1 not in lanes:
-            y = []
-            for m in self.model:
-                if m.f != -1 and m.f != -4:
-                    x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
-                x = self._run_layer(m, x, x2, cbufs)
-                y.append(x if m.i in self.save else None)
+            y, marks = [], []
+            if profile:     # reference :252-260,270-271: per-layer time / GFLOPS / params / type.  One stream, HIP events around
+                flog, prev_log = [], ops._launch_log         # every layer, GFLOPS from the algorithmic FLOPs of its GEMM launches
+                ops.set_launch_log(flog)
+            try:
+                for m in self.model:
+                    if m.f != -1 and m.f != -4:
+                        x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+                    if profile:
+                        e0, e1, n0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), len(flog)
+                        e0.record()
+                    x = self._run_layer(m, x, x2, cbufs)
+                    if profile:
+                        e1.record()
+                        marks.append((m, e0, e1, sum(rec[1] for rec in flog[n0:])))
+                    y.append(x if m.i in self.save else None)
+            finally:
+                if profile:
+                    ops.set_launch_log(prev_log)
+            if profile:
+                torch.cuda.synchronize(x[0].device if isinstance(x, (tuple, list)) else x.device)
+                self.profile_ms = [(m.i, m.type, e0.elapsed_time(e1), fl / 1e9, m.np) for m, e0, e1, fl in marks]
+                logger.info(f"{'time (ms)':>10s} {'GFLOPS':>10s} {'params':>10s}  {'module'}")
+                for i, t, ms, gf, np_ in self.profile_ms:
+                    logger.info(f"{ms:10.2f} {gf:10.2f} {np_:10.0f}  {t}")
+                logger.info('%.1fms total' % sum(r[2] for r in self.profile_ms))
             return x
         main = torch.cuda.current_stream(x.device)
         side = self.__dict__.get("_side_stream")

@@ -205,12 +205,9 @@ def conv2d(x, pk, act, residual=None, out=None, out_dtype=None):
     return out
 
 
-# cft_bottleneck covers 64 channels (3x3 weights LDS-resident, one workgroup per CU) and 128 channels (activation patch
-# resident, weights streamed through a 4-slot LDS ring; two workgroups per CU: 147-173 vs 220-234 us for the two launches it
-# replaces - profiles/r02_bottleneck128.md).  CFT_FUSE128=0 in the environment restores the two-launch path for the
-# 128-channel stage (A/B runs); CFT_BNECK128=b / persistent select the earlier implementations of the kernel.
-import os as _os
-FUSED_BOTTLENECK_WIDTHS = (64,) if _os.environ.get("CFT_FUSE128", "1") == "0" else (64, 128)
+# cft_bottleneck covers 64 and 128 channels (activation patch resident in LDS, weights streamed through a 4-slot LDS ring, two
+# workgroups per CU: 147-173 vs 220-234 us for the two launches it replaces at 128 channels - profiles/r02_bottleneck128.md).
+FUSED_BOTTLENECK_WIDTHS = (64, 128)
 
 
 def bottleneck_fusable(x, pk1, pk2, act1, act2):
@@ -303,12 +300,20 @@ def focus_s2d(img, dtype):
         # with (batch*channel, row, 1 pixel, W "channels") the output is exactly the contiguous NCHW image
         if img.dtype not in COMPUTE_DTYPES:
             raise TypeError(f"focus_s2d: unsupported image dtype {img.dtype}")
-        if img.stride(0) != 3 * img.stride(1) or W % 4:
-            raise ValueError("focus_s2d: non-fp32 / strided images need uniform batch/channel strides and W % 4 == 0")
+        if W % 4:
+            raise ValueError("focus_s2d: image width must be a multiple of 4")
         flat = torch.empty((B, 3, H, W), dtype=torch.float32, device=img.device)
-        st = _lib.load().cft_to_nhwc(img.data_ptr(), _dt(img.dtype), img.stride(1), img.stride(3), img.stride(2), 0,
-                                     flat.data_ptr(), W, 0, B * 3, W, W, H, 1, CFT_F32, _stream())
-        _lib.check(st, "cft_to_nhwc(image)")
+        lib, es = _lib.load(), img.element_size()
+        sb, sc, sh, sw = img.stride()
+        if sb == 3 * sc:          # (batch, channel) collapse into one uniform axis of 3B planes
+            calls = [(img.data_ptr(), flat.data_ptr(), (sc, sw, sh, 0), B * 3, H)]
+        elif sc == H * sh:        # the three planes of an image are stacked rows, e.g. f[:, :3] / f[:, 3:] of the callers'
+            calls = [(img.data_ptr(), flat.data_ptr(), (sb, sw, sh, 0), B, 3 * H)]      # [B,6,H,W] batch (test.py:112-113)
+        else:                     # arbitrary strides: one launch per image
+            calls = [(img.data_ptr() + b * sb * es, flat.data_ptr() + b * 3 * H * W * 4, (sc, sw, sh, 0), 3, H) for b in range(B)]
+        for src, dst, (s0, s1, s2, s3), nb, nh in calls:
+            _lib.check(lib.cft_to_nhwc(src, _dt(img.dtype), s0, s1, s2, s3, dst, W, 0, nb, W, W, nh, 1, CFT_F32, _stream()),
+                       "cft_to_nhwc(image)")
         img = flat
     out = new_nhwc(B, H // 2, W // 2, 16, dtype, img.device)
     st = _lib.load().cft_focus_s2d(img.data_ptr(), out.data_ptr(), B, H, W, _dt(dtype), _stream())
@@ -517,7 +522,10 @@ def batchnorm_train(y32, C, bn, act, residual=None, out=None, out_dtype=None):
     M = B * H * W
     ws = torch.empty((lib.cft_batchnorm_train_workspace(M, C),), dtype=torch.uint8, device=y32.device)
     track = bn.track_running_stats and bn.running_mean is not None
-    mom = 0.0 if bn.momentum is None else float(bn.momentum)
+    if bn.momentum is not None:
+        mom = float(bn.momentum)
+    else:   # torch: momentum=None is the cumulative moving average, factor 1 / num_batches_tracked (after the increment)
+        mom = 1.0 / (int(bn.num_batches_tracked) + 1) if (track and bn.num_batches_tracked is not None) else 0.0
     st = lib.cft_batchnorm_train(y32.data_ptr(), ldx, 0, M, C, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                  bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
                                  mom, float(bn.eps), rp, ldr, 0, rdt, out.data_ptr(), ldy, 0, act, _dt(out.dtype),

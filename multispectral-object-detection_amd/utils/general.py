@@ -37,7 +37,11 @@ def batched_nms(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnos
     scratch = torch.empty((B * ((cap + 3) // 4 * 4) * 32,), dtype=torch.uint8, device=prediction.device)
     dets = torch.zeros((B, max_det, 6), dtype=torch.float32, device=prediction.device)
     counts = torch.zeros((B,), dtype=torch.int32, device=prediction.device)
-    allow = classes if isinstance(classes, torch.Tensor) and classes.dtype == torch.uint8 else _class_table(classes, nc, prediction.device)
+    if isinstance(classes, torch.Tensor) and classes.dtype == torch.uint8 and classes.numel() == nc and classes.is_cuda \
+            and classes.device == prediction.device and classes.is_contiguous():
+        allow = classes                       # a ready-made [nc] allow-table on the device (the kernel indexes it by class id)
+    else:                                     # anything else is a collection of class ids (reference :505-506)
+        allow = _class_table(classes.tolist() if isinstance(classes, torch.Tensor) else classes, nc, prediction.device)
     st = _lib.load().cft_nms(prediction.data_ptr(), B, rows, no, float(conf_thres), float(iou_thres), int(bool(agnostic)),
                              int(multi_label), allow.data_ptr() if allow is not None else None, int(max_det), int(max_nms),
                              scratch.data_ptr(), scratch.numel(), dets.data_ptr(), counts.data_ptr(), _stream())

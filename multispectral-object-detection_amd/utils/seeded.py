@@ -83,3 +83,51 @@ def seeded_inputs(batch, height, width, seed=0):
     rgb = torch.rand((batch, 3, height, width), generator=g0, dtype=torch.float32)
     ir = torch.rand((batch, 3, height, width), generator=g1, dtype=torch.float32)
     return rgb, ir
+
+
+def default_init_tensor(key, ref, seed=0):
+    """Value for state-dict entry ``key`` drawn from the distribution the REFERENCE's own constructor uses
+    (models/common.py:41-43 nn.Conv2d default = kaiming_uniform(a=sqrt 5) = U(+-1/sqrt(fan_in)); :459-473,582-591
+    Linear N(0, 0.02) / bias 0, LayerNorm 1 / 0; models/yolo_test.py:274-282 Detect bias), with the tensors that the
+    constructor leaves at the identity (BatchNorm affine + running statistics, ``pos_emb``) seeded MILDLY so that they
+    still take part in the arithmetic.  Per-key generator like ``seeded_tensor``: reference, oracle and HIP model
+    get identical values without a checkpoint."""
+    import math
+    shape = tuple(ref.shape)
+    g = _gen(seed, "dinit/" + key)
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked" or key.endswith("anchors") or key.endswith("anchor_grid"):
+        return ref.clone()
+    if leaf == "pos_emb":
+        return 0.02 * _randn(shape, g)
+    if leaf == "running_mean":
+        return 0.02 * _randn(shape, g)
+    if leaf == "running_var":
+        return _rand(shape, g, 0.9, 1.1)
+    is_norm = (".bn." in key) or (".ln_" in key) or (".ln_f." in key)
+    if is_norm:
+        if ".bn." in key:
+            return _rand(shape, g, 0.95, 1.05) if leaf == "weight" else 0.02 * _randn(shape, g)
+        return torch.ones(shape) if leaf == "weight" else torch.zeros(shape)          # LayerNorm: the constructor's 1 / 0
+    if leaf == "weight" and len(shape) == 4:
+        b = 1.0 / math.sqrt(shape[1] * shape[2] * shape[3])
+        return _rand(shape, g, -b, b)
+    if leaf == "weight" and len(shape) == 2:
+        return 0.02 * _randn(shape, g)
+    if leaf == "bias" and ".m." in key and ".conv." not in key and len(shape) == 1 and ".mlp." not in key and ".sa." not in key:
+        # Detect level i: model.<last>.m.<i>.bias = default U(+-1/sqrt(fan_in)) (taken as 0.01-scale here; fan-in is not
+        # in the key) + _initialize_biases: obj += log(8 / (640/s)^2), cls += log(0.6 / (nc - 0.99)), s = 8 * 2^i
+        lvl = int(key.split(".")[-2])
+        na = 3
+        no = shape[0] // na
+        bvec = 0.01 * _randn((na, no), g)
+        bvec[:, 4] += math.log(8 / (640 / (8.0 * 2 ** lvl)) ** 2)
+        bvec[:, 5:] += math.log(0.6 / (no - 5 - 0.99))
+        return bvec.reshape(-1)
+    return torch.zeros(shape)                                                              # Linear biases: 0
+
+
+def default_init_state_dict(template, seed=0):
+    """Like ``seeded_state_dict`` but with the reference constructor's weight distributions (see ``default_init_tensor``):
+    the 'freshly built model' regime, where activations shrink through the depth and 16-bit storage errors are small."""
+    return {k: (default_init_tensor(k, v, seed).to(v.dtype) if v.is_floating_point() else v.clone()) for k, v in template.items()}

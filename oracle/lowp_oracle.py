@@ -141,3 +141,22 @@ class LowpOracle:
         sd = {k: v.float() if v.is_floating_point() else v for k, v in sd.items()}
         dt = self.dtype
         return _forward(self.cfg, sd, rgb.float(), ir.float(), lambda x: x.to(dt).float(), self.res32)
+
+
+class AutocastOracle:
+    """The fp32 oracle evaluated under ``torch.autocast("cpu", dtype)`` - the reference's own low-precision forward
+    (train.py:755 ``amp.autocast``; the reference ``Model`` under CPU bf16 autocast is what tests/golden/lowp_ref.pt
+    records).  ``OracleModel`` issues the same ATen ops in the same order as the reference modules, so the autocast
+    policy casts the same tensors: tests/test_oracle_golden.py pins this class to those recorded outputs.  Used where
+    the reference tree is not available (GPU box) as the live comparator 'how far is the REFERENCE's own 16-bit
+    forward from its fp32 forward on these weights and this shape'."""
+
+    def __init__(self, cfg, dtype=torch.bfloat16):
+        from .cft_oracle import OracleModel
+        self.model, self.dtype = OracleModel(cfg), dtype
+
+    @torch.no_grad()
+    def __call__(self, sd, rgb, ir):
+        with torch.autocast("cpu", dtype=self.dtype):
+            pred, raw = self.model(sd, rgb, ir)
+        return pred.float(), [r.float() for r in raw]

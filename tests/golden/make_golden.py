@@ -202,8 +202,70 @@ def make_letterbox_golden():
     torch.save(cases, os.path.join(HERE, "letterbox_cases.pt"))
 
 
+# name, config name, batch, H, W, fused, seed - weights from utils/seeded.default_init_state_dict (the reference constructor's
+# distributions): the regime in which north_star's 1e-2 bf16 bound is asserted outright
+DINIT_CASES = [
+    ("dinit_l_x3_flir_256", "cfg3", 1, 256, 256, True, 0),
+    ("dinit_s_x3_rect", "yolov5s_fusion_transformerx3_vedai", 2, 192, 320, False, 1),
+    ("dinit_x_x3_256", "cfg5", 1, 256, 256, True, 2),
+    ("dinit_s_x4_256", "yolov5s_fusion_transformer_vedai", 1, 256, 256, True, 3),
+]
+
+
+def make_lowp_golden():
+    """The reference's OWN low-precision forward: its unmodified ``Model`` under ``torch.autocast("cpu", bfloat16)`` (what
+    train.py:755 ``amp.autocast`` does on a GPU; CPU autocast only offers bf16) on the same seeded weights / inputs
+    as the fp32 goldens.  Written to tests/golden/lowp_ref.pt: {case: raw_bf16 list}; and, for the DINIT_CASES (reference
+    constructor weight distributions), the fp32 outputs too.  This pins the 16-bit bound to the reference instead of to a
+    storage model of ours: the HIP bf16 path must be at least as close to the reference's fp32 output as the
+    reference's own bf16 forward is."""
+    install_reference()
+    sys.path.insert(0, ROOT)
+    import msod_amd  # noqa: F401
+    from msod_amd.models.configs import named_config
+    from msod_amd.utils.seeded import default_init_state_dict, seeded_inputs, seeded_state_dict
+    from models.yolo_test import Model  # the reference
+    torch.set_num_threads(os.cpu_count())
+    out = {}
+    for name, cfg_name, b, h, w, fused, seed in CASES + DINIT_CASES:
+        dinit = name.startswith("dinit_")
+        cfg = named_config(cfg_name)
+        torch.manual_seed(0)
+        model = Model(cfg).eval()
+        sd = (default_init_state_dict if dinit else seeded_state_dict)(model.state_dict(), seed)
+        model.load_state_dict(sd)
+        if fused:
+            model.fuse()
+        rgb, ir = seeded_inputs(b, h, w, seed)
+        with torch.no_grad():
+            pred, raw = model(rgb, ir)
+            pred, raw = pred.clone(), [r.clone() for r in raw]      # Detect mutates / reuses its list
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                _, raw16 = model(rgb, ir)
+        assert all(r.dtype == torch.bfloat16 for r in raw16)
+        store16 = [r.clone() for r in raw16]                         # kept in bf16 (lossless, half the bytes)
+        raw16 = [r.float() for r in raw16]
+        flat = lambda rs: torch.cat([r.reshape(-1) for r in rs])    # noqa: E731
+        sig = (flat(raw16).sigmoid() - flat(raw).sigmoid()).abs()
+        rec = {"case": dict(name=name, cfg=cfg_name, batch=b, height=h, width=w, fused=fused, seed=seed, dinit=dinit),
+               "raw_bf16": store16, "sig_err_bf16": sig.max().item(), "torch": torch.__version__}
+        if dinit:
+            rec["raw"] = raw             # pred is a function of raw (Detect decode); the oracle supplies it
+        else:       # must be the forward the fp32 golden holds
+            g = torch.load(os.path.join(HERE, name + ".pt"), weights_only=False)
+            assert all(torch.equal(a, c) for a, c in zip(raw, g["raw"])), name
+        out[name] = rec
+        print(f"{name:22s} reference bf16-autocast vs its fp32: max sigmoid-space err {sig.max().item():.3e}, "
+              f"rms logit err {(flat(raw16) - flat(raw)).pow(2).mean().sqrt().item():.3e}, logit std {flat(raw).std().item():.3f}")
+    path = os.path.join(HERE, "lowp_ref.pt")
+    torch.save(out, path)
+    print(f"lowp_ref.pt {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "letterbox":
+    if len(sys.argv) > 1 and sys.argv[1] == "lowp":
+        make_lowp_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "letterbox":
         make_letterbox_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "train":
         make_train_golden()
@@ -217,3 +279,4 @@ if __name__ == "__main__":
         make_checkpoint()
         make_train_golden()
         make_letterbox_golden()
+        make_lowp_golden()

@@ -70,6 +70,13 @@ def _worker(rank, world, port, n_pairs, q):
     both = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(both, t)
     ok = ok and float(both[0]) == float(both[1])           # MAX over ranks: identical on every rank
+    # the self-check that an N > 1 bench line carries: rank count, per-rank clocks, gathered rows == each rank's local rows
+    local = torch.full((2, 3), 600.0 + rank)
+    chk = D.gather_selfcheck(local, og2.drain(), rank, world, elapsed_local=D.timed_steps.last_local_elapsed)
+    ok = ok and chk["n_ranks_seen"] == world and chk["rows_ok"] and len(chk["per_rank_elapsed_s"]) == world
+    ok = ok and chk["per_rank_elapsed_s"][1] >= 4 * 0.02 * 0.9 and chk["gather_ms"] >= 0.0
+    bad = D.gather_selfcheck(local + (1.0 if rank == 1 else 0.0), og2.drain(), rank, world)     # a rank whose rows did NOT arrive
+    ok = ok and not bad["rows_ok"]
     q.put((rank, ok, tuple(out.shape)))
     dist.barrier()
     dist.destroy_process_group()

@@ -31,7 +31,7 @@ from test_oracle_golden import load_case
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(__file__)
 GOLDEN = sorted(p for p in glob.glob(os.path.join(HERE, "golden", "*.pt"))
-                if not os.path.basename(p).startswith(("nms_", "ref_ckpt", "s_x3_train", "letterbox_")))
+                if not os.path.basename(p).startswith(("nms_", "ref_ckpt", "s_x3_train", "letterbox_", "lowp_")))
 IDS = [os.path.basename(p)[:-3] for p in GOLDEN]
 
 F16_SIGMOID_ATOL = 1e-2     # north_star's 16-bit bound, met in fp16 (measured <= 2e-3)
@@ -177,6 +177,161 @@ def test_cfg5_one_pair_at_1280(dev):
     _check_fp32(pred, raw, want_pred, want_raw)
     pred, raw = _run(model, rgb, ir, dev, torch.float16)
     _check_f16(pred, raw, want_pred, want_raw)
+
+
+# ------------------------------------------------------------------------- the 16-bit bound, pinned to the REFERENCE's own bf16 forward
+# tests/golden/lowp_ref.pt (make_golden.py `lowp`): the reference's unmodified Model under torch.autocast("cpu", bfloat16) on
+# the golden weights/inputs, plus four cases with the reference CONSTRUCTOR's weight distributions (`dinit_*`).
+LOWP_REF = torch.load(os.path.join(HERE, "golden", "lowp_ref.pt"), weights_only=False)
+REF_BF16_RMS_RATIO, REF_BF16_MAX_RATIO = 1.10, 1.30   # HIP bf16 error level vs the reference's own bf16 error level
+
+
+def _lowp_case(name):
+    from msod_amd.models.configs import named_config
+    from msod_amd.models.yolo_test import Model
+    from msod_amd.utils.seeded import default_init_state_dict, seeded_inputs, seeded_state_dict
+    rec = LOWP_REF[name]
+    c = rec["case"]
+    cfg = named_config(c["cfg"])
+    model = Model(cfg)
+    model.load_state_dict((default_init_state_dict if c["dinit"] else seeded_state_dict)(model.state_dict(), c["seed"]))
+    if c["fused"]:
+        model.fuse()
+    rgb, ir = seeded_inputs(c["batch"], c["height"], c["width"], c["seed"])
+    return rec, cfg, model, rgb, ir
+
+
+@pytest.mark.parametrize("name", [n for n in LOWP_REF if not n.startswith("dinit_")])
+def test_bf16_is_at_least_as_close_to_fp32_as_the_references_own_bf16(dev, name):
+    """HIP bf16 vs the reference's fp32 output, against the reference's OWN bf16-autocast forward vs the same fp32
+    output (recorded in the build container): rms error <= 1.10 x, max sigmoid-space error <= 1.30 x (+1e-3) the
+    reference's.  (Two bf16 realisations differ element by element - roundings flip and cascade - so the comparison is
+    of error levels.)"""
+    rec, cfg, model, rgb, ir = _lowp_case(name)
+    g = torch.load(os.path.join(HERE, "golden", name + ".pt"), weights_only=False)
+    ref16 = [r.float() for r in rec["raw_bf16"]]
+    pred, raw = _run(model, rgb, ir, dev, torch.bfloat16)
+    assert _rms_rel(raw, g["raw"]) <= REF_BF16_RMS_RATIO * _rms_rel(ref16, g["raw"]) + 2e-4
+    assert _sig_err(raw, g["raw"]) <= REF_BF16_MAX_RATIO * _sig_err(ref16, g["raw"]) + 1e-3
+
+
+@pytest.mark.parametrize("name", [n for n in LOWP_REF if n.startswith("dinit_")])
+def test_reference_constructor_weights_meet_1e2_in_bf16(dev, name):
+    """north_star's bounds asserted outright - fp32 1e-3, fp16 1e-2, **bf16 1e-2** in sigmoid space - on weights drawn
+    from the reference constructor's own distributions (kaiming-uniform convs, N(0, 0.02) linears; BatchNorm statistics
+    and pos_emb mildly seeded), for the l, s, 4-GPT and x (cfg5) networks, vs the REFERENCE's recorded fp32 forward.
+    The reference's own bf16 forward is 1.1-1.4e-3 away there."""
+    from oracle.cft_oracle import OracleModel
+    rec, cfg, model, rgb, ir = _lowp_case(name)
+    want_pred, want_raw = OracleModel(cfg)(model.state_dict(), rgb, ir)
+    for a, b in zip(want_raw, rec["raw"]):
+        assert (a - b).abs().max().item() <= 2e-4            # the oracle reproduces the reference on these weights too
+    pred, raw = _run(model, rgb, ir, dev, torch.float32)
+    _check_fp32(pred, raw, want_pred, rec["raw"])
+    pred, raw = _run(model, rgb, ir, dev, torch.float16)
+    assert _sig_err(raw, rec["raw"]) <= 1e-2
+    pred, raw = _run(model, rgb, ir, dev, torch.bfloat16)
+    assert _sig_err(raw, rec["raw"]) <= 1e-2, f"bf16 sigmoid-space error {_sig_err(raw, rec['raw']):.3e}"
+    assert (pred[..., 4:] - want_pred[..., 4:]).abs().max().item() <= 1e-2
+    ref16 = [r.float() for r in rec["raw_bf16"]]
+    assert _rms_rel(raw, rec["raw"]) <= 1.25 * _rms_rel(ref16, rec["raw"]) + 2e-4
+
+
+def test_cfg3_at_the_benchmarked_batch_of_64(dev):
+    """The configuration bench.py times: yolov5l + CFTx3, 640x640, SIXTY-FOUR pairs per GPU, BN folded, HIP-graph replay - at
+    this M the dispatcher picks the 256x256 16-wave tiles, the chunk-major K walk and the fused Bottleneck kernels, which
+    the 2-pair test above never reaches.  Pairs 0 and 63 vs the oracle in bf16 and fp16; for bf16 also against the live
+    reference-style bf16 forward (oracle under CPU autocast, pinned to the reference in tests/test_oracle_golden.py)."""
+    from msod_amd.utils.seeded import seeded_inputs
+    from oracle.cft_oracle import OracleModel
+    from oracle.lowp_oracle import AutocastOracle
+    cfg, model, sd = _seeded("cfg3", 0)
+    rgb, ir = seeded_inputs(64, 640, 640, 0)
+    idx = [0, 63]
+    model.fuse()
+    fsd = model.state_dict()
+    want_pred, want_raw = OracleModel(cfg)(fsd, rgb[idx], ir[idx])
+    _, ref16 = AutocastOracle(cfg)(fsd, rgb[idx], ir[idx])
+    model = model.to(dev)
+    x, x2 = rgb.to(dev), ir.to(dev)
+    for dtype in (torch.bfloat16, torch.float16):
+        model.set_compute_dtype(dtype)
+        with torch.no_grad():
+            model.capture(64, 640, 640)
+            pred, raw = model(x, x2)
+            torch.cuda.synchronize()
+            pred, raw = pred[idx].cpu(), [r[idx].cpu() for r in raw]
+        model.release_graphs()
+        assert torch.isfinite(pred).all()
+        if dtype == torch.float16:
+            _check_f16(pred, raw, want_pred, want_raw)
+        else:
+            _check_bf16(pred, raw, want_pred, want_raw)
+            assert _rms_rel(raw, want_raw) <= REF_BF16_RMS_RATIO * _rms_rel(ref16, want_raw) + 2e-4
+            assert _sig_err(raw, want_raw) <= REF_BF16_MAX_RATIO * _sig_err(ref16, want_raw) + 1e-3
+
+
+def test_cfg5_bf16_and_cfg4_at_640(dev):
+    """Coverage holes named by VERDICT r2: cfg5 (yolov5x x3 CFT, 1280x1280) in bf16, and cfg4 (LLVIP yaml, nc = 1) at its
+    own 640x640 shape in fp32 / fp16 / bf16; bf16 against the oracle and the live reference-style bf16 level."""
+    from msod_amd.utils.seeded import seeded_inputs
+    from oracle.cft_oracle import OracleModel
+    from oracle.lowp_oracle import AutocastOracle
+    for cfg_name, size, seed in (("cfg5", 1280, 5), ("cfg4", 640, 4)):
+        cfg, model, sd = _seeded(cfg_name, seed)
+        rgb, ir = seeded_inputs(1, size, size, seed)
+        model.fuse()
+        fsd = model.state_dict()
+        want_pred, want_raw = OracleModel(cfg)(fsd, rgb, ir)
+        _, ref16 = AutocastOracle(cfg)(fsd, rgb, ir)
+        if cfg_name == "cfg4":
+            pred, raw = _run(model, rgb, ir, dev, torch.float32)
+            assert pred.shape == (1, 25200, 6)
+            _check_fp32(pred, raw, want_pred, want_raw)
+            pred, raw = _run(model, rgb, ir, dev, torch.float16)
+            _check_f16(pred, raw, want_pred, want_raw)
+        pred, raw = _run(model, rgb, ir, dev, torch.bfloat16)
+        _check_bf16(pred, raw, want_pred, want_raw)
+        assert _rms_rel(raw, want_raw) <= REF_BF16_RMS_RATIO * _rms_rel(ref16, want_raw) + 2e-4
+        assert _sig_err(raw, want_raw) <= REF_BF16_MAX_RATIO * _sig_err(ref16, want_raw) + 1e-3
+
+
+def test_float_channel_slices_of_a_six_channel_batch(dev):
+    """the reference's callers pass `img[:, :3]`, `img[:, 3:]` of ONE float [B,6,H,W] batch (test.py:112-113,
+    train.py:716-717); fp32 compute (the non-fused Focus path), fp16 images with bf16 compute, and the training forward."""
+    from oracle.cft_oracle import OracleModel
+    g, cfg, model, rgb, ir = load_case([p for p in GOLDEN if p.endswith("s_1cft_256.pt")][0])
+    want_pred, want_raw = OracleModel(cfg)(model.state_dict(), rgb, ir)
+    f6 = torch.cat([rgb, ir], 1).to(dev)
+    model = model.to(dev).set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        pred, raw = model(f6[:, :3], f6[:, 3:])
+    _check_fp32(pred.cpu(), [r.cpu() for r in raw], want_pred, want_raw)
+    model.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        pred, raw = model(f6.half()[:, :3], f6.half()[:, 3:])
+    _check_bf16(pred.cpu(), [r.cpu() for r in raw], want_pred, want_raw)
+    model.set_compute_dtype(torch.float32).train()
+    with torch.no_grad():
+        raws = model(f6[:, :3], f6[:, 3:])
+        raws2 = model(f6[:, :3].contiguous(), f6[:, 3:].contiguous())
+    assert all(torch.equal(a, b) for a, b in zip(raws, raws2))
+
+
+def test_fresh_model_runs_in_its_declared_precision(dev):
+    """`Model(cfg).cuda()` without set_compute_dtype() computes in Model.compute_dtype (bf16), not in fp32."""
+    from msod_amd.models.common import Focus
+    from msod_amd.models.configs import named_config
+    from msod_amd.models.yolo_test import Model
+    model = Model(named_config("cfg1")).to(dev)
+    assert model.compute_dtype == torch.bfloat16
+    assert all(m.compute_dtype == torch.bfloat16 for m in model.modules() if isinstance(m, Focus))
+    seen = []
+    hook = model.model[1].register_forward_hook(lambda mod, inp, out: seen.append(out.dtype))
+    with torch.no_grad():
+        model(torch.rand(1, 3, 64, 64, device=dev), torch.rand(1, 3, 64, 64, device=dev))
+    hook.remove()
+    assert seen == [torch.bfloat16]
 
 
 # ------------------------------------------------------------------------- structural properties
@@ -337,6 +492,24 @@ def test_small_odd_shapes_match_oracle(dev, shape):
     _check_fp32(pred, raw, want_pred, want_raw)
     pred, raw = _run(model, rgb, ir, dev, torch.float16)
     _check_f16(pred, raw, want_pred, want_raw)
+
+
+def test_profile_flag_reports_per_layer_times(dev):
+    """forward_once(profile=True) (reference models/yolo_test.py:252-260,270-271): one row per top-level layer with its
+    time, the algorithmic GFLOP of its GEMM launches, parameter count and type; the outputs are those of a normal forward."""
+    g, cfg, model, rgb, ir = load_case([p for p in GOLDEN if p.endswith("s_1cft_256.pt")][0])
+    model = model.to(dev).set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        want, _ = model(rgb.to(dev), ir.to(dev))
+        got, _ = model(rgb.to(dev), ir.to(dev), profile=True)
+    assert torch.equal(want, got)
+    rows = model.profile_ms
+    assert len(rows) == len(model.model) and [r[0] for r in rows] == list(range(len(rows)))
+    assert all(r[2] > 0 for r in rows) and rows[0][1] == "Focus" and rows[-1][1] == "Detect"
+    from oracle.cft_oracle import algorithmic_flops
+    total = sum(r[3] for r in rows) * 1e9
+    want_fl = algorithmic_flops(cfg, rgb.shape[2], rgb.shape[3])
+    assert abs(total / rgb.shape[0] - want_fl["total"]) / want_fl["total"] < 0.02     # convs + linears + QK^T / AV
 
 
 def test_bad_image_sizes_raise(dev):

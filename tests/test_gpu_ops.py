@@ -267,7 +267,7 @@ def test_errors_are_loud(dev):
         ops.conv2d(torch.zeros(1, 8, 4, 4, device=dev, dtype=torch.float16), pk, 0, out_dtype=torch.bfloat16)   # fp16 in, bf16 out
 
 
-TILE_VARIANTS = [1, 2, 4, 6, 7, 8, 23, 27, 30, 32, 33, 51, 60, 63, 70, 71, 72, 73, 74, 75, 80, 81]
+TILE_VARIANTS = [1, 2, 4, 6, 7, 8, 23, 27, 30, 32, 33, 51, 60, 63, 70, 71, 72, 73, 74, 75]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
@@ -292,6 +292,41 @@ def test_conv2d_every_tile_configuration(dev, dtype, variant):
     finally:
         lib.cft_set_conv_variant(0)
     assert rel_err(to_cpu_f32(y), ref) < tol(dtype), f"variant {variant}: rel err {rel_err(to_cpu_f32(y), ref):.3e}"
+
+
+@pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(64, 40, 256, 256, True), (64, 20, 512, 512, False)], ids=["p4_256ch", "p5_512ch"])
+def test_conv3x3_wide_layers_at_the_benchmarked_row_count(dev, dtype, shape):
+    """The kernel configuration bench.py actually times on the wide 3x3 layers: M = 64 x 40 x 40 =
+    102 400 / 64 x 20 x 20 = 25 600 rows with Cin in {256, 512}, where the dispatcher picks the 256x256 16-wave tile AND
+    the chunk-major K walk (Cin >= 256).  The automatic choice and the forced big-tile variants (27 = 256x256, 60 =
+    128x256, 51 = 192x128) against F.conv2d, and bit-identical among themselves (every variant walks K alike)."""
+    from msod_amd import _lib, ops
+    B, HW, Cin, Cout, use_res = shape
+    x = _q(_rnd(B, Cin, HW, HW, seed=51), dtype)
+    w = _q(_rnd(Cout, Cin, 3, 3, seed=52, scale=1.0 / math.sqrt(Cin * 9)), dtype)
+    b = _rnd(Cout, seed=53, scale=0.5)
+    ref = F.silu(F.conv2d(x, w, b, 1, 1))
+    res = None
+    if use_res:
+        res = _q(_rnd(*ref.shape, seed=54), dtype)
+        ref = ref + res
+    pk = ops.pack_conv(w, b, dtype, device=dev)
+    xd = to_dev_nhwc(x, dev, dtype)
+    rd = None if res is None else to_dev_nhwc(res, dev, dtype)
+    lib = _lib.load()
+    outs = {}
+    try:
+        for variant in (0, 27, 60, 51):
+            lib.cft_set_conv_variant(variant)
+            y = ops.conv2d(xd, pk, 1, residual=rd)
+            torch.cuda.synchronize()
+            outs[variant] = to_cpu_f32(y)
+    finally:
+        lib.cft_set_conv_variant(0)
+    for variant, got in outs.items():
+        assert rel_err(got, ref) < tol(dtype), f"variant {variant}: rel err {rel_err(got, ref):.3e}"
+        assert torch.equal(got, outs[0]), f"variant {variant} differs from the automatic choice"
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
@@ -375,25 +410,6 @@ def test_bottleneck_fused_is_bit_identical(dev, shortcut, hw, dtype, C):
     assert torch.equal(d[:, :C].float().cpu(), x), "input slice untouched"
     with pytest.raises(RuntimeError):
         ops.bottleneck(xin, pk1, pk2, shortcut, out=xin)         # in-place is refused (halo reads)
-    if C == 128:      # the other implementations of the same kernel: persistent one-workgroup-per-CU (9128), 16-KiB K tiles with 8 / 4 waves (9100 / 9004)
-        from msod_amd import _lib
-        for variant in (9128, 9004, 9100):
-            _lib.load().cft_set_conv_variant(variant)
-            try:
-                other = ops.bottleneck(xin, pk1, pk2, shortcut)
-                torch.cuda.synchronize()
-            finally:
-                _lib.load().cft_set_conv_variant(0)
-            assert torch.equal(other.float().cpu(), two.float().cpu()), variant
-    if C == 64:       # the other implementation: 3x3 weights LDS-resident, one workgroup per CU (9640)
-        from msod_amd import _lib
-        _lib.load().cft_set_conv_variant(9640)
-        try:
-            other = ops.bottleneck(xin, pk1, pk2, shortcut)
-            torch.cuda.synchronize()
-        finally:
-            _lib.load().cft_set_conv_variant(0)
-        assert torch.equal(other.float().cpu(), two.float().cpu()), 9640
     ref = O.bottleneck(sd, "m.", x, shortcut)
     assert rel_err(to_cpu_f32(fused), ref) < 2 * tol(dtype)   # two 16-bit roundings (hidden tensor, output)
 
@@ -423,7 +439,7 @@ def test_bottleneck_pack_w2_stage_images(dev, dtype):
 @pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
 def test_bottleneck128_many_tiles_per_workgroup(dev, dtype):
     """More tiles than workgroup slots (12 x 50 = 600 > 512, so workgroups start while others are mid-tile), at the
-    BASELINE map size of the 128-channel stage: both two-per-CU kernels equal the two cft_conv2d launches bit for bit."""
+    BASELINE map size of the 128-channel stage: the fused kernel equals the two cft_conv2d launches bit for bit."""
     from msod_amd import _lib, ops
     C, B, H, W = 128, 12, 80, 80
     g = torch.Generator().manual_seed(5)
@@ -433,7 +449,7 @@ def test_bottleneck128_many_tiles_per_workgroup(dev, dtype):
     x.copy_(torch.randn(x.shape, generator=g).to(dev))
     two = ops.conv2d(ops.conv2d(x, pk1, 1), pk2, 1, residual=x)
     lib = _lib.load()
-    for variant in (0, 9100):
+    for variant in (0,):
         lib.cft_set_conv_variant(variant)
         try:
             y = ops.bottleneck(x, pk1, pk2, True)
@@ -481,8 +497,9 @@ def test_plain_nchw_tensor_into_a_module(dev, dtype):
     assert torch.equal(z[:, :12].float().cpu(), _q(_rnd(2, 12, 5, 7, seed=82), dtype)) and z[:, 12:].abs().max() == 0
 
 
+ALT_VARIANTS = []     # GEMM variants with a different schedule / epilogue / work split but the same arithmetic (filled below)
 STAGGERED_CASES = [
-    # B, H, W, Cin, Cout, k, s, residual          (variants 80 / 81: the staggered two-group kernels)
+    # B, H, W, Cin, Cout, k, s, residual
     (2, 33, 31, 64, 320, 3, 1, True),       # ragged M, N tail over three / two tiles, border taps
     (3, 20, 20, 32, 256, 3, 2, False),      # Cin < K step: several taps per K tile (the non-branch-free advance), stride 2
     (1, 16, 16, 1024, 512, 1, 1, False),    # 1x1, long K (16 K tiles)
@@ -493,12 +510,12 @@ STAGGERED_CASES = [
 
 
 @pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
-@pytest.mark.parametrize("variant", [80, 81])
+@pytest.mark.parametrize("variant", ALT_VARIANTS)
 @pytest.mark.parametrize("case", STAGGERED_CASES, ids=[f"s{i}" for i in range(len(STAGGERED_CASES))])
-def test_staggered_group_kernels_are_bit_identical(dev, dtype, variant, case):
-    """conv_gemm8 / conv_gemm8n (two wave groups one barrier apart, counted vmcnt, 2 / 3 LDS buffers) against the
-    plain 128x128 kernel (variant 2): same fragments, same k order -> same bits, on shapes that stress the K-tile
-    run-ahead (1 .. 18 K tiles, K tails, zero-page tiles beyond K, taps that straddle tiles) and the tile edges."""
+def test_alternative_gemm_variants_are_bit_identical(dev, dtype, variant, case):
+    """GEMM variants that change the schedule, the epilogue or the split of the work but not the arithmetic, against the
+    plain 128x128 kernel (variant 2): same fragments, same k order -> same bits, on shapes that stress K tails, taps that
+    straddle K tiles, 1 .. 18 K tiles and the tile edges."""
     from msod_amd import _lib, ops
     B, H, W, Cin, Cout, k, s_, use_res = case
     x = _q(_rnd(B, Cin, H, W, seed=91), dtype)

@@ -101,7 +101,7 @@ def test_pack_conv_layout(dtype):
 def test_c_abi_exports_every_declared_symbol():
     """The shared library must load (no GPU needed) and export exactly what include/cft_hip.h declares."""
     lib = _lib.load()
-    assert lib.cft_abi_version() == 3
+    assert lib.cft_abi_version() == _lib.ABI_VERSION
     header = open(os.path.join(ROOT, "include", "cft_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:int|long|const char\*)\s+(cft_\w+)\s*\(", header, re.M))
     assert declared == set(_lib.SIGNATURES) | {"cft_last_error"}, declared ^ (set(_lib.SIGNATURES) | {"cft_last_error"})

@@ -1,0 +1,4 @@
+#!/bin/bash
+# Probe build of libcft_hip.so: the timing-probe / A-B variants (ABLATE / ABL template arguments, variants 1xx..97xx of
+# cft_set_conv_variant) are compiled only here - the product library (tools/build.sh, __graft_entry__.build) has none.
+exec "$(dirname "$0")/build.sh" -DCFT_PROBES "$@"

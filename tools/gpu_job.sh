@@ -1,0 +1,52 @@
+#!/bin/bash
+# One entry point for every GPU-box job of a round (replaces the per-experiment run_r2*.sh scripts of round 2):
+#   gpurun --timeout N -- bash tools/gpu_job.sh <job> [args]
+# Every job writes under gpurun_out/<job>/ ; summaries worth keeping are copied to profiles/ by hand afterwards.
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"; export TMPDIR=/tmp
+JOB=${1:-help}; shift
+O=gpurun_out/$JOB; mkdir -p $O
+case $JOB in
+  parity)      # the round-3 parity tests + the bench line with parity_at_bench_shape / sustained
+    timeout 1500 python -m pytest tests -q -m gpu -x -k "references_own_bf16 or reference_constructor or benchmarked or cfg5_bf16 or channel_slices_of_a_six or fresh_model or train_forward or profile_flag" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt
+    tail -5 $O/tests.log
+    timeout 900 python bench.py > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee -a $O/summary.txt
+    tail -3 $O/bench.log; head -c 600 $O/bench.json ;;
+  tests)       # full -m gpu suite + smoke
+    timeout 2400 python -m pytest tests -q -m gpu -x "$@" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt
+    tail -5 $O/tests.log
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/summary.txt; tail -3 $O/smoke.log ;;
+  gemm)        # tools/gemm_bench.py A/B: gpu_job.sh gemm <variants> [only-filter]
+    timeout 1200 python tools/gemm_bench.py --variants "$1" ${2:+--only "$2"} --out $JOB/gemm.json > $O/gemm.log 2>&1; echo "gemm rc=$?" | tee $O/summary.txt
+    grep -E "^variant|^best" $O/gemm.log ;;
+  bench)       # headline bench line (+ extra args)
+    timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
+    tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
+  evidence)    # PMC traffic passes, bench line, rocprofv3 kernel stats (single- and two-stream)
+    bash tools/pmc_traffic.sh $O/traffic > $O/traffic.log 2>&1
+    python tools/traffic_summary.py $O/traffic $O/traffic.json config=cfg3 batch=64 size=640 dtype=bf16 | tee $O/summary.txt
+    rm -rf $O/traffic; cp $O/traffic.json profiles/r03_traffic.json
+    timeout 900 python bench.py > $O/bench_bs64.json 2> $O/bench.log; echo "bench rc=$?" | tee -a $O/summary.txt
+    cp gpurun_out/bench_families.json $O/gemm_families_cfg3.json
+    timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof1 --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f16-leg --no-overlap --sustained-steps 0 --no-parity > $O/prof1.log 2>&1; echo "prof single-stream rc=$?" | tee -a $O/summary.txt
+    cp $(ls $O/prof1/*/*kernel_stats.csv | head -1) $O/bench_bs64_kernel_stats.csv; rm -rf $O/prof1
+    timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof2 --output-format csv -- python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity > $O/prof2.log 2>&1; echo "prof two-stream rc=$?" | tee -a $O/summary.txt
+    cp $(ls $O/prof2/*/*kernel_stats.csv | head -1) $O/bench_bs64_kernel_stats_two_streams_40steps.csv; rm -rf $O/prof2
+    head -c 1500 $O/bench_bs64.json ;;
+  configs)     # bench lines of the other BASELINE configurations (single-GPU share)
+    X="--no-cpu-baseline --no-f16-leg --sustained-steps 0"
+    timeout 300 python bench.py --batch 8 $X > $O/bench_bs8.json 2> $O/bs8.log; echo "bs8 rc=$?"
+    timeout 300 python bench.py --config cfg2 --batch 16 --dtype f32 --no-cpu-baseline --sustained-steps 0 > $O/bench_cfg2.json 2> $O/cfg2.log; echo "cfg2 rc=$?"
+    timeout 300 python bench.py --config cfg4 --batch 64 $X > $O/bench_cfg4.json 2> $O/cfg4.log; echo "cfg4 rc=$?"
+    timeout 400 python bench.py --config cfg5 --batch 16 --size 1280 $X > $O/bench_cfg5.json 2> $O/cfg5.log; echo "cfg5 rc=$?"
+    python - <<'PY'
+import json
+for n in ("bs8", "cfg2", "cfg4", "cfg5"):
+    try:
+        d = json.load(open(f"gpurun_out/configs/bench_{n}.json"))
+        print(n, d["dtype"], d["value"], d["ms_per_step"], d["roofline"]["frac"], d.get("parity_at_bench_shape"))
+    except Exception as e:
+        print(n, "failed", e)
+PY
+    ;;
+  *) echo "jobs: parity | tests [pytest args] | gemm <variants> [filter] | bench [args] | evidence | configs" ;;
+esac
