@@ -242,6 +242,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run both backbones on one HIP stream")
     ap.add_argument("--sustained-steps", type=int, default=500, help="extra >= 10 s leg at N = 1 (0 = skip)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed configuration")
+    ap.add_argument("--conv-variant", type=int, default=0, help="A/B runs: cft_set_conv_variant() for the whole process (0 = automatic)")
     args = ap.parse_args()
 
     rank, world, local = D.init_from_env()
@@ -251,6 +252,9 @@ def main():
     torch.cuda.set_device(dev)
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
 
+    if args.conv_variant:
+        from msod_amd import _lib
+        _lib.load().cft_set_conv_variant(args.conv_variant)
     log(f"rank {rank}/{world} building {args.config}")
     cfg = named_config(args.config)
     model = Model(cfg)
@@ -335,7 +339,8 @@ def main():
             "config": {"workload": f"{args.config} ({WORKLOADS.get(args.config, args.config)}) two-stream forward, "
                                    f"{args.size}x{args.size}, {args.batch} pairs/GPU, BN folded, pre-NMS detections",
                        "pairs_per_gpu": args.batch, "image_size": args.size, "parallelism": f"batch-shard x{world}",
-                       "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap},
+                       "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap,
+                       **({"conv_variant": args.conv_variant} if args.conv_variant else {})},
             "sustained": sustained, "multi_gpu_selfcheck": selfcheck,
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear family; incl. the dedicated Focus kernel and the fused 64- / 128-channel Bottleneck kernels: 2 + 27 launches of the cfg3 forward)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),

@@ -54,6 +54,9 @@ __device__ __forceinline__ int fast_div(int n, uint32_t mul, uint32_t sh) {
 }
 
 __device__ __attribute__((aligned(16))) uint32_t cft_zero_page[4] = {0u, 0u, 0u, 0u};
+// UNIK path: weight rows beyond N point at this zero REGION and still advance along K (no per-step select): 64 KiB >= 2 * Kpad + 128
+constexpr int CFT_ZERO_REGION_BYTES = 65536;
+__device__ __attribute__((aligned(128))) uint32_t cft_zero_region[CFT_ZERO_REGION_BYTES / 4];   // zero-initialised
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -194,7 +197,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc
 
 // ABLATE (tuning only, bit mask): 1 = no global loads after the first tile (compute-only bound); 2 = no MFMA
 // (staging-only bound); 16 = no epilogue (no bias/activation/residual/stores).
-template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0>
+// UNIK (uniform K walk; needs GLDS, Cin % K-step == 0, Kpad == K): every thread of the workgroup is at the same (tap, channel
+// chunk) in a K step, so the walk over taps / chunks is SCALAR (SGPR) arithmetic and a thread only keeps constant pointers:
+// the staging block shrinks from ~80 to ~25 instructions per K step (16 waves issue it in lock step after every barrier,
+// with the matrix pipe idle).  Same fetches, same LDS image, same products and k order: bit-identical to the generic path.
+template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0, bool UNIK = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvParams p) {
   constexpr int NTHR = 64 * WGM * WGN;
   constexpr int GE = Elem<T>::GE;
@@ -331,6 +338,51 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
         *reinterpret_cast<gran_t*>(sB + (buf_) * B_BYTES + (r0 + i * RPP) * 128 + swz) = rb[i];        \
   }
 
+  // ---- UNIK: constant per-thread pointers + scalar walk ----
+  const unsigned char* ua[UNIK ? A_PER : 1];     // x + (pixel origin + this thread's k-granule) : only dereferenced for in-image taps
+  const unsigned char* ub[UNIK ? B_PER : 1];     // w + row n, this thread's k-granule (rows >= N: the zero region)
+  int u_tap = 0, u_kw = 0;                       // scalar: tap index and its column
+  long u_offa = 0;                               // scalar: byte offset of (tap, chunk) inside the pixel neighbourhood
+  int u_offb = 0;                                // scalar: byte offset of the K step inside a weight row
+  if constexpr (UNIK) {
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) ua[i] = p.x + ((long)a_off[i] + g * GE) * ES;
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int n = n0 + r0 + i * RPP;
+      ub[i] = (n < p.N) ? p.w + ((long)n * p.Kpad + g * GE) * ES
+                        : reinterpret_cast<const unsigned char*>(cft_zero_region) + g * GE * ES;
+    }
+  }
+// One K step of the UNIK path: 2 scalar adds per operand + per A row {mask test, 64-bit add, select}; then the scalar advance
+// (tap-major: next 64-channel chunk, after Cin channels the next tap; chunk-major: next tap, after nine taps the next chunk).
+#define CFT_LOAD_TILE_U(buf_)                                                                          \
+  {                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < A_PER; ++i) {                                                \
+      const bool v = (a_mask[i] >> u_tap) & 1u;                                                        \
+      const unsigned char* src = v ? ua[i] + u_offa : zero_page;                                       \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src,                                               \
+          (lds_void_t*)(sA + (buf_) * A_BYTES + i * (RPP * 128) + wave * 1024), 16, 0, 0);             \
+    }                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < B_PER; ++i) {                                                \
+      if (BN % RPP != 0 && i * RPP + wave * 8 >= BN) continue;                                         \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(ub[i] + u_offb),                                  \
+          (lds_void_t*)(sB + (buf_) * B_BYTES + i * (RPP * 128) + wave * 1024), 16, 0, 0);             \
+    }                                                                                                  \
+    if (chunk_major) {                                                                                 \
+      ++u_tap; ++u_kw; u_offa += (long)p.ldx * ES; u_offb += p.Cin * ES;                               \
+      if (u_kw == 3) { u_kw = 0; u_offa += (long)row_step * ES; }                                      \
+      if (u_tap == 9) { u_tap = 0; u_offa += ((long)BK - 3L * p.W * p.ldx) * ES; u_offb += (BK - 9 * p.Cin) * ES; } \
+    } else {                                                                                           \
+      u_offb += BK * ES; u_offa += BK * ES; u_ci += BK;                                                \
+      if (u_ci == p.Cin) {                                                                             \
+        u_ci = 0; ++u_tap; ++u_kw; u_offa += (long)tap_step * ES;                                      \
+        if (u_kw == p.KS) { u_kw = 0; u_offa += (long)row_step * ES; }                                 \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+  int u_ci = 0;                                  // scalar: channel offset of the K step inside its tap (tap-major walk)
+
   f32x4_t acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -340,13 +392,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
   if constexpr (!(ABLATE & 32)) conv_load_bias<WN>(p, n0, wn, lane, bias_v);
 
   const int nk = p.Kpad / BK;
-  CFT_LOAD_TILE(0, 0)
+  if constexpr (UNIK) { CFT_LOAD_TILE_U(0) } else { CFT_LOAD_TILE(0, 0) }
   CFT_STORE_TILE(0)
   __syncthreads();
   const int lrow = lane & 15, lgrp = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk && !(ABLATE & 1)) CFT_LOAD_TILE(kt + 1, buf ^ 1)
+    if (kt + 1 < nk && !(ABLATE & 1)) {
+      if constexpr (UNIK) { CFT_LOAD_TILE_U(buf ^ 1) } else { CFT_LOAD_TILE(kt + 1, buf ^ 1) }
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kg = ks * 4 + lgrp;
@@ -373,6 +427,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
     __syncthreads();
   }
 #undef CFT_LOAD_TILE
+#undef CFT_LOAD_TILE_U
 #undef CFT_STORE_TILE
 
   if constexpr (ABLATE & 16) {   // timing probe: no epilogue (keep the accumulators alive)
@@ -397,6 +452,7 @@ static void set_magic(int d, uint32_t& mul, uint32_t& sh) {
   sh = (uint32_t)(k - 32);
 }
 
+
 // Tile variants.  0 = automatic choice; the others force one configuration (tuning / A-B tests).
 int g_conv_variant = 0;   // also read by bottleneck.hip in probe builds (-DCFT_PROBES)
 extern "C" int cft_set_conv_variant(int v) {
@@ -405,40 +461,50 @@ extern "C" int cft_set_conv_variant(int v) {
   return old;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0>
+template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0, bool UNIK = false>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
   constexpr int smem_bytes = 2 * (BM + BN) * 128;
-  cft_allow_lds<&conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE>>(smem_bytes);
+  cft_allow_lds<&conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE, UNIK>>(smem_bytes);
   ConvParams q = p;
   const int tilesM = (p.M + BM - 1) / BM;
   q.tilesN = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE>), dim3(tilesM * q.tilesN), dim3(64 * WGM * WGN), smem_bytes, stream, q);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE, UNIK>), dim3(tilesM * q.tilesN), dim3(64 * WGM * WGN), smem_bytes, stream, q);
   return cft_check_launch("conv_gemm_kernel");
+}
+
+// Automatic choice: the uniform-K-walk form of a tile configuration whenever the layer allows it (every layer of the CFT
+// networks except the Focus conv and the 80 / 160 / 320-channel layers of yolov5x); variant 900 forces the generic path (A/B).
+template <typename T, int BM, int BN, int WGM, int WGN>
+static int launch_auto(const ConvParams& p, hipStream_t stream) {
+  constexpr int BK = 8 * Elem<T>::GE;
+  const bool unik = g_conv_variant != 900 && p.Cin % BK == 0 && p.Kpad == p.K && 2L * p.Kpad * (long)sizeof(T) + 128 <= CFT_ZERO_REGION_BYTES;
+  if (unik) return launch_conv<T, BM, BN, WGM, WGN, true, 0, true>(p, stream);
+  return launch_conv<T, BM, BN, WGM, WGN, true>(p, stream);
 }
 
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   switch (g_conv_variant) {
     case 1: return launch_conv<T, 128, 128, 2, 2, false>(p, stream);   // register-staged baseline
-    case 2: return launch_conv<T, 128, 128, 2, 2, true>(p, stream);
-    case 4: return launch_conv<T, 128, 64, 2, 2, true>(p, stream);
-    case 6: return launch_conv<T, 256, 64, 4, 2, true>(p, stream);
-    case 7: return launch_conv<T, 64, 128, 2, 2, true>(p, stream);
-    case 8: return launch_conv<T, 64, 64, 2, 2, true>(p, stream);
-    case 23: return launch_conv<T, 128, 128, 2, 4, true>(p, stream);
-    case 27: return launch_conv<T, 256, 256, 4, 4, true>(p, stream);
-    case 30: return launch_conv<T, 512, 128, 8, 2, true>(p, stream);
-    case 32: return launch_conv<T, 512, 64, 8, 2, true>(p, stream);
-    case 33: return launch_conv<T, 256, 128, 4, 2, true>(p, stream);
-    case 51: return launch_conv<T, 192, 128, 2, 4, true>(p, stream);
-    case 60: return launch_conv<T, 128, 256, 4, 4, true>(p, stream);
-    case 63: return launch_conv<T, 64, 128, 2, 4, true>(p, stream);
-    case 70: return launch_conv<T, 256, 160, 8, 2, true>(p, stream);   // 80/160-wide tiles: yolov5x / yolov5m channel counts
-    case 71: return launch_conv<T, 256, 160, 4, 2, true>(p, stream);
-    case 72: return launch_conv<T, 128, 160, 4, 2, true>(p, stream);
-    case 73: return launch_conv<T, 256, 80, 4, 1, true>(p, stream);
-    case 74: return launch_conv<T, 256, 80, 8, 1, true>(p, stream);
-    case 75: return launch_conv<T, 128, 80, 4, 1, true>(p, stream);
+    case 2: return launch_auto<T, 128, 128, 2, 2>(p, stream);
+    case 4: return launch_auto<T, 128, 64, 2, 2>(p, stream);
+    case 6: return launch_auto<T, 256, 64, 4, 2>(p, stream);
+    case 7: return launch_auto<T, 64, 128, 2, 2>(p, stream);
+    case 8: return launch_auto<T, 64, 64, 2, 2>(p, stream);
+    case 23: return launch_auto<T, 128, 128, 2, 4>(p, stream);
+    case 27: return launch_auto<T, 256, 256, 4, 4>(p, stream);
+    case 30: return launch_auto<T, 512, 128, 8, 2>(p, stream);
+    case 32: return launch_auto<T, 512, 64, 8, 2>(p, stream);
+    case 33: return launch_auto<T, 256, 128, 4, 2>(p, stream);
+    case 51: return launch_auto<T, 192, 128, 2, 4>(p, stream);
+    case 60: return launch_auto<T, 128, 256, 4, 4>(p, stream);
+    case 63: return launch_auto<T, 64, 128, 2, 4>(p, stream);
+    case 70: return launch_auto<T, 256, 160, 8, 2>(p, stream);   // 80/160-wide tiles: yolov5x / yolov5m channel counts
+    case 71: return launch_auto<T, 256, 160, 4, 2>(p, stream);
+    case 72: return launch_auto<T, 128, 160, 4, 2>(p, stream);
+    case 73: return launch_auto<T, 256, 80, 4, 1>(p, stream);
+    case 74: return launch_auto<T, 256, 80, 8, 1>(p, stream);
+    case 75: return launch_auto<T, 128, 80, 4, 1>(p, stream);
 #ifdef CFT_PROBES   // timing probes / A-B variants (tools/build_probes.sh): results of 1xx/2xx/3xx/16xx are wrong by construction
     case 3223: return launch_conv<T, 128, 128, 2, 4, true, 32>(p, stream);   // 32xx: bias loaded at the epilogue (round-1 placement)
     case 3251: return launch_conv<T, 192, 128, 2, 4, true, 32>(p, stream);
@@ -459,9 +525,9 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   const long kCUs = 192;   // accept a configuration once it yields >= 0.75 workgroups per CU (256 CUs)
   if (p.N <= 64) {
-    if (tiles(256, 64) >= kCUs) return launch_conv<T, 256, 64, 4, 2, true>(p, stream);
-    if (tiles(128, 64) >= kCUs) return launch_conv<T, 128, 64, 2, 2, true>(p, stream);
-    return launch_conv<T, 64, 64, 2, 2, true>(p, stream);
+    if (tiles(256, 64) >= kCUs) return launch_auto<T, 256, 64, 4, 2>(p, stream);
+    if (tiles(128, 64) >= kCUs) return launch_auto<T, 128, 64, 2, 2>(p, stream);
+    return launch_auto<T, 64, 64, 2, 2>(p, stream);
   }
   if (p.N > 64) {
     // channel counts that are multiples of 80 / 160 but not of 128 (yolov5x: 80, 160, 320): the 128/256-wide tiles
@@ -470,24 +536,24 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
     const long p128 = (long)((p.N + 127) / 128) * 128, p256 = (long)((p.N + 255) / 256) * 256;
     const long cur = (p.N <= 128) ? p128 : ((p256 * 100 <= p128 * 115) ? p256 : p128);
     const long p160 = (long)((p.N + 159) / 160) * 160, p80 = (long)((p.N + 79) / 80) * 80;
-    if (p160 * 100 <= cur * 90 && p160 <= p80 && tiles(128, 160) >= kCUs / 2) return launch_conv<T, 128, 160, 4, 2, true>(p, stream);
-    if (p80 * 100 <= cur * 90 && p80 < p160 && tiles(128, 80) >= kCUs / 2) return launch_conv<T, 128, 80, 4, 1, true>(p, stream);
+    if (p160 * 100 <= cur * 90 && p160 <= p80 && tiles(128, 160) >= kCUs / 2) return launch_auto<T, 128, 160, 4, 2>(p, stream);
+    if (p80 * 100 <= cur * 90 && p80 < p160 && tiles(128, 80) >= kCUs / 2) return launch_auto<T, 128, 80, 4, 1>(p, stream);
   }
   if (p.N <= 128) {
     // 192x128 with 8 waves is the largest 128-wide tile of which TWO workgroups fit a CU (80 KiB LDS each): the
     // store/residual burst of one workgroup's epilogue overlaps the other's K loop (+5..8 % over 512x128x16w).
-    if (tiles(192, 128) >= 2 * kCUs) return launch_conv<T, 192, 128, 2, 4, true>(p, stream);
-    if (tiles(128, 128) >= 2 * kCUs) return launch_conv<T, 128, 128, 2, 4, true>(p, stream);
-    return launch_conv<T, 64, 128, 2, 4, true>(p, stream);          // few tiles: 3 workgroups of 8 waves per CU
+    if (tiles(192, 128) >= 2 * kCUs) return launch_auto<T, 192, 128, 2, 4>(p, stream);
+    if (tiles(128, 128) >= 2 * kCUs) return launch_auto<T, 128, 128, 2, 4>(p, stream);
+    return launch_auto<T, 64, 128, 2, 4>(p, stream);          // few tiles: 3 workgroups of 8 waves per CU
   }
   // wide layers: prefer 256-wide tiles unless the N tail would waste much more than 128-wide tiles do
   const long pad256 = (long)((p.N + 255) / 256) * 256, pad128 = (long)((p.N + 127) / 128) * 128;
   const bool wide_ok = pad256 * 100 <= pad128 * 115;
-  if (wide_ok && p.Kpad >= 256 && tiles(256, 256) >= kCUs) return launch_conv<T, 256, 256, 4, 4, true>(p, stream);
-  if (wide_ok && tiles(128, 256) >= kCUs) return launch_conv<T, 128, 256, 4, 4, true>(p, stream);   // e.g. CFT fc2 at M = 8192
-  if (tiles(192, 128) >= 2 * kCUs) return launch_conv<T, 192, 128, 2, 4, true>(p, stream);
-  if (tiles(128, 128) >= 2 * kCUs) return launch_conv<T, 128, 128, 2, 4, true>(p, stream);
-  return launch_conv<T, 64, 128, 2, 4, true>(p, stream);
+  if (wide_ok && p.Kpad >= 256 && tiles(256, 256) >= kCUs) return launch_auto<T, 256, 256, 4, 4>(p, stream);
+  if (wide_ok && tiles(128, 256) >= kCUs) return launch_auto<T, 128, 256, 4, 4>(p, stream);   // e.g. CFT fc2 at M = 8192
+  if (tiles(192, 128) >= 2 * kCUs) return launch_auto<T, 192, 128, 2, 4>(p, stream);
+  if (tiles(128, 128) >= 2 * kCUs) return launch_auto<T, 128, 128, 2, 4>(p, stream);
+  return launch_auto<T, 64, 128, 2, 4>(p, stream);
 }
 
 extern "C" int cft_conv2d(const void* x, const void* w, const float* bias, const void* res, void* y,

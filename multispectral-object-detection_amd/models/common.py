@@ -168,7 +168,7 @@ class Conv(_Packed):
 
     def _pack(self, dtype, device, cin_pad=None):
         w, b = _folded(self)
-        return ops.pack_conv(w, b, dtype, s=self.conv.stride[0], cin_pad=cin_pad, device=device)
+        return ops.pack_conv(w, b, dtype, s=self.conv.stride[0], cin_pad=cin_pad or self.cin_pad, device=device)
 
     cin_pad = None      # Focus sets 16 on its inner Conv (space-to-depth output is padded to 16 channels)
 

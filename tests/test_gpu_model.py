@@ -311,9 +311,12 @@ def test_float_channel_slices_of_a_six_channel_batch(dev):
     with torch.no_grad():
         pred, raw = model(f6.half()[:, :3], f6.half()[:, 3:])
     _check_bf16(pred.cpu(), [r.cpu() for r in raw], want_pred, want_raw)
+    from msod_amd import ops
     model.set_compute_dtype(torch.float32).train()
     with torch.no_grad():
+        ops.manual_dropout_seed(5)           # (training mode: the GPT dropout masks are drawn per call)
         raws = model(f6[:, :3], f6[:, 3:])
+        ops.manual_dropout_seed(5)
         raws2 = model(f6[:, :3].contiguous(), f6[:, 3:].contiguous())
     assert all(torch.equal(a, b) for a, b in zip(raws, raws2))
 

@@ -497,7 +497,8 @@ def test_plain_nchw_tensor_into_a_module(dev, dtype):
     assert torch.equal(z[:, :12].float().cpu(), _q(_rnd(2, 12, 5, 7, seed=82), dtype)) and z[:, 12:].abs().max() == 0
 
 
-ALT_VARIANTS = []     # GEMM variants with a different schedule / epilogue / work split but the same arithmetic (filled below)
+ALT_VARIANTS = [0, 27, 51]   # automatic choice / forced big tiles with the uniform-K-walk address path (UNIK) where the layer allows it,
+# against variant 900 = the generic per-thread address path
 STAGGERED_CASES = [
     # B, H, W, Cin, Cout, k, s, residual
     (2, 33, 31, 64, 320, 3, 1, True),       # ragged M, N tail over three / two tiles, border taps
@@ -506,16 +507,19 @@ STAGGERED_CASES = [
     (2, 12, 12, 128, 128, 3, 1, True),      # the 128-channel Bottleneck shape
     (1, 9, 11, 80, 160, 3, 1, False),       # K = 720 -> Kpad 768: K tail inside the last tile, taps straddle K tiles
     (1, 8, 8, 64, 8, 1, 1, False),          # ONE K tile (shorter than the prologue's run-ahead), N = 8
+    (1, 12, 12, 256, 64, 3, 1, True),       # Cin >= 256: the chunk-major K walk (36 K steps), border taps on every side
+    (2, 9, 9, 512, 40, 3, 2, False),        # chunk-major, stride 2, N tail inside a 64-wide tile
 ]
 
 
-@pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 @pytest.mark.parametrize("variant", ALT_VARIANTS)
 @pytest.mark.parametrize("case", STAGGERED_CASES, ids=[f"s{i}" for i in range(len(STAGGERED_CASES))])
 def test_alternative_gemm_variants_are_bit_identical(dev, dtype, variant, case):
-    """GEMM variants that change the schedule, the epilogue or the split of the work but not the arithmetic, against the
-    plain 128x128 kernel (variant 2): same fragments, same k order -> same bits, on shapes that stress K tails, taps that
-    straddle K tiles, 1 .. 18 K tiles and the tile edges."""
+    """The uniform-K-walk address path (constant per-thread pointers + scalar tap / chunk walk, taken automatically when
+    Cin is a multiple of the K step) against the generic per-thread address path (variant 900): same fetches, same LDS
+    image, same k order -> same bits; on shapes that stress K tails, taps that straddle K tiles (those stay on the generic
+    path), 1 .. 72 K steps, the chunk-major walk, borders and tile edges."""
     from msod_amd import _lib, ops
     B, H, W, Cin, Cout, k, s_, use_res = case
     x = _q(_rnd(B, Cin, H, W, seed=91), dtype)
@@ -525,7 +529,7 @@ def test_alternative_gemm_variants_are_bit_identical(dev, dtype, variant, case):
     xd = to_dev_nhwc(x, dev, dtype)
     lib = _lib.load()
     outs = {}
-    for v in (2, variant):
+    for v in (900, variant):
         lib.cft_set_conv_variant(v)
         try:
             y0 = ops.conv2d(xd, pk, 1)
@@ -534,7 +538,7 @@ def test_alternative_gemm_variants_are_bit_identical(dev, dtype, variant, case):
             torch.cuda.synchronize()
         finally:
             lib.cft_set_conv_variant(0)
-    assert torch.equal(outs[2].float().cpu(), outs[variant].float().cpu())
+    assert torch.equal(outs[900].float().cpu(), outs[variant].float().cpu())
     ref = F.silu(F.conv2d(x, w, b, s_, k // 2))
     got = to_cpu_f32(outs[variant])[:, :Cout]
     if not use_res:

@@ -64,7 +64,8 @@ def test_hip_train_forward_matches_oracle(dev, dtype):
             ref16, _ = OracleModel(cfg)(sd, rgb, ir, train=True)
         ref16 = torch.cat([r.float().reshape(-1) for r in ref16])
         err, ref_err = (got.sigmoid() - want.sigmoid()).abs().max().item(), (ref16.sigmoid() - want.sigmoid()).abs().max().item()
-        assert err <= 2.5e-2 and err <= 1.3 * ref_err + 1e-3, (err, ref_err)
+        assert err <= 6e-2 and err <= 1.3 * ref_err + 1e-3, (err, ref_err)   # (measured 3.5e-2 vs 4.8e-2 for the reference-style forward:
+        # batch statistics of a 2-image batch amplify 16-bit storage errors)
     new = model.state_dict()
     tol = {torch.float32: 1e-4, torch.float16: 2e-2, torch.bfloat16: 6e-2}[dtype]
     for k, v in g["stats"].items():

@@ -34,6 +34,9 @@ SHAPES = [
     ("bneck 3x3 512->512 @20", 64, 20, 20, 512, 512, 3, 1, False, 9),
     ("1x1 1024->1024 @20", 64, 20, 20, 1024, 1024, 1, 1, False, 6),
     ("SPP cv2 1x1 2048->1024 @20", 64, 20, 20, 2048, 1024, 1, 1, False, 2),
+    # tile-count quantisation probe: the same layer at M = 65 536 rows (256 tiles of 256 = exactly one round of 256 CUs)
+    ("quant 3x3 256->256 @32 (M=65536) +res", 64, 32, 32, 256, 256, 3, 1, True, 0),
+    ("quant 1x1 256->256 @32 (M=65536)", 64, 32, 32, 256, 256, 1, 1, False, 0),
     ("x5 3x3 160->160 @160 +res", 16, 160, 160, 160, 160, 3, 1, True, 0),
     ("x5 3x3 320->320 @80 +res", 16, 80, 80, 320, 320, 3, 1, True, 0),
     ("x5 3x3 80->80 @320 +res", 16, 320, 320, 80, 80, 3, 1, True, 0),

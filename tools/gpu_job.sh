@@ -18,6 +18,16 @@ case $JOB in
   gemm)        # tools/gemm_bench.py A/B: gpu_job.sh gemm <variants> [only-filter]
     timeout 1200 python tools/gemm_bench.py --variants "$1" ${2:+--only "$2"} --out $JOB/gemm.json > $O/gemm.log 2>&1; echo "gemm rc=$?" | tee $O/summary.txt
     grep -E "^variant|^best" $O/gemm.log ;;
+  ab900)       # A/B of the automatic choice (variant 0) against variant 900: bit-identity tests, per-shape A/B, whole-forward A/B
+    timeout 1200 python -m pytest tests -q -m gpu -x -k "alternative_gemm or test_conv2d or bottleneck or channel_slices or fresh_model or train_forward or profile_flag or wide_layers" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt
+    tail -4 $O/tests.log
+    timeout 900 python tools/gemm_bench.py --variants 900,0 --out $JOB/gemm.json > $O/gemm.log 2>&1; echo "gemm rc=$?" | tee -a $O/summary.txt
+    grep -E "^variant|^best" $O/gemm.log
+    X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
+    for v in 900 0 900 0; do timeout 300 python bench.py $X --conv-variant $v > $O/bench_v$v.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/bench_v$v.json'));print('variant $v', d['value'], d['ms_per_step'], d['roofline']['frac'])" | tee -a $O/summary.txt; done ;;
+  batches)     # pairs/s against the batch per GPU (tile-count quantisation on 256 CUs: 64 pairs = 400 tiles of 256 rows at 40x40)
+    X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
+    for b in 64 80 48 96 64 80; do timeout 300 python bench.py $X --batch $b > $O/bench_b$b.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/bench_b$b.json'));print('batch $b', d['value'], d['ms_per_step'], d['roofline']['frac'])" | tee -a $O/summary.txt; done ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
