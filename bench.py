@@ -187,7 +187,8 @@ def parity_at_bench_shape(dtype_name, got_raw, want_raw, ref16_raw=None, n_ref=0
 
 class ClockSampler:
     """Shader clock during a sustained leg, from the amdgpu sysfs DPM table (the line marked '*' of pp_dpm_sclk), sampled
-    at 10 Hz by a thread; ``mean_mhz`` is None where the file is not readable."""
+    at 10 Hz by a thread; ``mean_mhz`` is None where the file is not readable.  Coarse: the table has few levels and the
+    driver reports the level, not the instantaneous clock - the sustained pairs/s next to the 20-step value is the evidence."""
 
     def __init__(self):
         import glob
@@ -242,6 +243,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run both backbones on one HIP stream")
     ap.add_argument("--sustained-steps", type=int, default=500, help="extra >= 10 s leg at N = 1 (0 = skip)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed configuration")
+    ap.add_argument("--in-flight", type=int, default=2, help="forwards in flight (own graphs, buffers and streams each); 1 = one at a time")
     ap.add_argument("--conv-variant", type=int, default=0, help="A/B runs: cft_set_conv_variant() for the whole process (0 = automatic)")
     args = ap.parse_args()
 
@@ -267,40 +269,62 @@ def main():
     rgb, ir = rgb.to(dev), ir.to(dev)
 
     log("weights loaded, packing + capturing")
+    k_fly = 1 if args.no_graph else max(1, args.in_flight)
     with torch.no_grad():
         if args.no_graph:
-            step_fn = lambda: model.forward_once(rgb, ir)   # noqa: E731
-            pred, _ = step_fn()
+            step_seq = lambda: model.forward_once(rgb, ir)   # noqa: E731
+            caps = []
         else:
-            cap = model.capture(args.batch, args.size, args.size)
-            cap.rgb.copy_(rgb)
-            cap.ir.copy_(ir)
-            step_fn = cap.replay_static
-            pred, _ = step_fn()
+            from msod_amd.graph import CapturedForward
+            caps = [model.capture(args.batch, args.size, args.size)] + [CapturedForward(model, args.batch, args.size, args.size)
+                                                                        for _ in range(k_fly - 1)]
+            for c in caps:
+                c.rgb.copy_(rgb)
+                c.ir.copy_(ir)
+            step_seq = caps[0].replay_static
+        pred, _ = step_seq()
         # N > 1: the all-gather of step i runs on RCCL's stream while the forward of step i+1 runs on the compute
         # stream (51.6 MB per rank per step would otherwise add ~10 % serial time); see distributed.OverlappedGather.
         gather = D.OverlappedGather(pred, world) if world > 1 else None
+        # A step = one forward over one batch of `--batch` pairs.  With --in-flight K (default 2) step t replays graph t % K on HIP
+        # stream t % K: consecutive steps are independent batches and overlap on the GPU (distributed.ForwardPipeline) - the
+        # low-occupancy stretches of one forward (CFT blocks with M = 8192, the single-stream head) run under the other's
+        # backbone convolutions.  --in-flight 1 = one forward at a time (also reported as "single_in_flight").
+        if k_fly > 1:
+            pipe = D.ForwardPipeline([(lambda c=c: c.replay_static()[0]) for c in caps],
+                                     [torch.cuda.Stream(device=dev) for _ in caps], gather)
+            step_fn = pipe.step
+        else:
+            step_fn = lambda: step_seq()[0]   # noqa: E731
+        torch.cuda.synchronize()
         # the measurement loop (warm-up, barrier + synchronize on both sides, MAX over ranks) is distributed.timed_steps:
         # the same code runs under tests/test_distributed_gloo.py with two CPU ranks
-        elapsed = D.timed_steps(lambda: step_fn()[0], args.steps, args.warmup, world=world, gather=gather,
-                                sync=torch.cuda.synchronize)
+        elapsed = D.timed_steps(step_fn, args.steps, max(args.warmup, k_fly), world=world, gather=gather, sync=torch.cuda.synchronize)
     assert torch.isfinite(pred).all(), "non-finite detections"
-    log(f"timed region: {elapsed:.3f} s for {args.steps} steps")
+    assert all(torch.equal(c.pred, pred) for c in caps[1:]), "the graphs in flight disagree"
+    log(f"timed region: {elapsed:.3f} s for {args.steps} steps ({k_fly} in flight)")
     local_elapsed = getattr(D.timed_steps, "last_local_elapsed", elapsed)
     n_par = 0 if args.no_parity else min(args.batch, 2 if args.no_cpu_baseline else 8)
     with torch.no_grad():
-        raw_now = step_fn()[1]
+        raw_now = step_seq()[1]
         torch.cuda.synchronize()
     got_raw = [r[:n_par].float().cpu() for r in raw_now] if n_par else None
+    single = None
+    if world == 1 and k_fly > 1:      # the same K steps, one forward at a time
+        with torch.no_grad():
+            el1 = D.timed_steps(lambda: step_seq()[0], args.steps, args.warmup, sync=torch.cuda.synchronize)
+        single = {"value": round(args.batch * args.steps / el1, 2), "unit": "image-pairs/sec", "ms_per_step": round(el1 / args.steps * 1e3, 3),
+                  "steps": args.steps, "note": "one forward in flight (each step starts when the previous one has finished)"}
+        log(f"single in flight: {single}")
     selfcheck = None
     if world > 1:       # evidence that every rank took part and that the gathered rows are the ranks' own rows
         selfcheck = D.gather_selfcheck(pred, gather.drain(), rank, world, elapsed_local=local_elapsed)
     sustained = None
     if world == 1 and args.sustained_steps > 0 and not args.no_graph:
         with ClockSampler() as clk, torch.no_grad():
-            el_s = D.timed_steps(lambda: step_fn()[0], args.sustained_steps, 2, sync=torch.cuda.synchronize)
+            el_s = D.timed_steps(step_fn, args.sustained_steps, 2, sync=torch.cuda.synchronize)
         sustained = {"steps": args.sustained_steps, "seconds": round(el_s, 3), "value": round(args.batch * args.sustained_steps / el_s, 2),
-                     "unit": "image-pairs/sec", "ms_per_step": round(el_s / args.sustained_steps * 1e3, 3), "mean_sclk_mhz": clk.mean_mhz,
+                     "unit": "image-pairs/sec", "ms_per_step": round(el_s / args.sustained_steps * 1e3, 3), "sclk_sysfs_level_mhz": clk.mean_mhz,
                      "sclk_samples": len(clk.samples)}
         log(f"sustained leg: {sustained}")
 
@@ -339,15 +363,18 @@ def main():
             "config": {"workload": f"{args.config} ({WORKLOADS.get(args.config, args.config)}) two-stream forward, "
                                    f"{args.size}x{args.size}, {args.batch} pairs/GPU, BN folded, pre-NMS detections",
                        "pairs_per_gpu": args.batch, "image_size": args.size, "parallelism": f"batch-shard x{world}",
-                       "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap,
+                       "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap, "forwards_in_flight": k_fly,
                        **({"conv_variant": args.conv_variant} if args.conv_variant else {})},
-            "sustained": sustained, "multi_gpu_selfcheck": selfcheck,
+            "sustained": sustained, "single_in_flight": single, "multi_gpu_selfcheck": selfcheck,
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear family; incl. the dedicated Focus kernel and the fused 64- / 128-channel Bottleneck kernels: 2 + 27 launches of the cfg3 forward)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic_from_profile(args, n_launch, abytes), "launches_per_step": n_launch,
                          "event_bracket_overhead_us": round(ovh * 1e6, 2),
                          "avg_launch_us": round(secs / n_launch * 1e6, 2),
                          "flops_per_step": flops, "gemm_time_share_of_step": round(secs * 1e3 / ms, 3),
+                         # per-launch times come from ONE forward on ONE stream; in the timed steps launches of two forwards (and of the
+                         # two backbones) overlap, so their sum may exceed ms_per_step.  whole_step = all algorithmic FLOPs / ms_per_step.
+                         "whole_step": {"tflops": round(flops / (ms * 1e-3) / 1e12 / max(world, 1) * world, 1), "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4)},
                          "by_block": {"backbone_head_convs": split.get("conv"), "cft_linears": split.get("linear"),
                                       "cft_block_whole": cft_block},
                          "top_shapes": [{"shape": k, "launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
@@ -358,15 +385,23 @@ def main():
             # rate and bytes as bf16, measured with the same loop
             model.set_compute_dtype(torch.float16)
             with torch.no_grad():
-                cap16 = model.capture(args.batch, args.size, args.size)
-                cap16.rgb.copy_(rgb)
-                cap16.ir.copy_(ir)
-                el16 = D.timed_steps(lambda: cap16.replay_static()[0], args.steps, args.warmup, sync=torch.cuda.synchronize)
+                from msod_amd.graph import CapturedForward
+                caps16 = [CapturedForward(model, args.batch, args.size, args.size) for _ in range(k_fly)]
+                for c in caps16:
+                    c.rgb.copy_(rgb)
+                    c.ir.copy_(ir)
+                cap16 = caps16[0]
+                if k_fly > 1:
+                    fn16 = D.ForwardPipeline([(lambda c=c: c.replay_static()[0]) for c in caps16], [torch.cuda.Stream(device=dev) for _ in caps16]).step
+                else:
+                    fn16 = lambda: cap16.replay_static()[0]   # noqa: E731
+                torch.cuda.synchronize()
+                el16 = D.timed_steps(fn16, args.steps, max(args.warmup, k_fly), sync=torch.cuda.synchronize)
             assert torch.isfinite(cap16.pred).all()
             got_raw16 = [r[:n_par].float().cpu() for r in cap16.raw] if n_par else None
             line["f16"] = {"value": round(args.batch * args.steps / el16, 2), "unit": "image-pairs/sec",
                            "ms_per_step": round(el16 / args.steps * 1e3, 3), "steps": args.steps,
-                           "note": "same workload with compute dtype fp16 (the reference's own GPU precision, test.py:66-68)"}
+                           "note": "same workload and step mode with compute dtype fp16 (the reference's own GPU precision, test.py:66-68)"}
             model.release_graphs()
             model.set_compute_dtype(dtype)
         want_raw = None

@@ -228,3 +228,28 @@ def gather_selfcheck(local, gathered, rank, world, elapsed_local=None, group=Non
         times.append((time.perf_counter() - t0) * 1e3)
     return {"n_ranks_seen": len(seen), "rows_ok": bool(rows_ok), "per_rank_elapsed_s": [round(float(t.item()), 6) for t in els],
             "gather_ms": round(statistics.median(times), 3)}
+
+
+class ForwardPipeline:
+    """Several forwards in flight: ``runners[i]()`` enqueues forward i (e.g. the replay of a captured HIP graph with its
+    OWN static input / output buffers) and returns its static output tensor; step t runs runner t % K on stream t % K,
+    so consecutive steps overlap on the GPU while the steps of one runner stay ordered on its stream.  Consecutive
+    inference steps are independent (different batches in deployment), which is what makes this legal; it is the compute
+    counterpart of ``OverlappedGather`` (step t's collective under step t + 1's forward).  ``gather`` (optional): every
+    step's output is submitted to it on the step's stream."""
+
+    def __init__(self, runners, streams=None, gather=None):
+        self.runners, self.streams, self.gather, self.tick = list(runners), streams, gather, 0
+        if streams is not None and len(streams) != len(self.runners):
+            raise ValueError("one stream per runner")
+
+    def step(self):
+        import contextlib
+        i = self.tick % len(self.runners)
+        self.tick += 1
+        ctx = torch.cuda.stream(self.streams[i]) if self.streams is not None else contextlib.nullcontext()
+        with ctx:
+            out = self.runners[i]()
+            if self.gather is not None and out is not None:
+                self.gather.submit(out)
+        return None        # (timed_steps must not submit a second time)

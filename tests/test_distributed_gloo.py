@@ -70,9 +70,26 @@ def _worker(rank, world, port, n_pairs, q):
     both = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(both, t)
     ok = ok and float(both[0]) == float(both[1])           # MAX over ranks: identical on every rank
+    slow_local = D.timed_steps.last_local_elapsed
+    # bench.py's step mode: two forwards in flight (ForwardPipeline), each step's output submitted to the overlapped gather
+    bufs = [torch.zeros(2, 3), torch.zeros(2, 3)]
+    n_run = [0, 0]
+
+    def runner(i):
+        def run():
+            n_run[i] += 1
+            bufs[i].fill_(1000.0 * (n_run[0] + n_run[1]) + rank)
+            return bufs[i]
+        return run
+
+    og3 = D.OverlappedGather(bufs[0], world)
+    pipe = D.ForwardPipeline([runner(0), runner(1)], None, og3)
+    D.timed_steps(pipe.step, steps=5, warmup=2, world=world, gather=og3)
+    ok = ok and n_run == [4, 3] and pipe.tick == 7                       # steps alternate between the two runners
+    ok = ok and torch.equal(og3.drain(), torch.cat([torch.full((2, 3), 7000.0 + r) for r in range(world)]))
     # the self-check that an N > 1 bench line carries: rank count, per-rank clocks, gathered rows == each rank's local rows
     local = torch.full((2, 3), 600.0 + rank)
-    chk = D.gather_selfcheck(local, og2.drain(), rank, world, elapsed_local=D.timed_steps.last_local_elapsed)
+    chk = D.gather_selfcheck(local, og2.drain(), rank, world, elapsed_local=slow_local)
     ok = ok and chk["n_ranks_seen"] == world and chk["rows_ok"] and len(chk["per_rank_elapsed_s"]) == world
     ok = ok and chk["per_rank_elapsed_s"][1] >= 4 * 0.02 * 0.9 and chk["gather_ms"] >= 0.0
     bad = D.gather_selfcheck(local + (1.0 if rank == 1 else 0.0), og2.drain(), rank, world)     # a rank whose rows did NOT arrive

@@ -28,6 +28,10 @@ case $JOB in
   batches)     # pairs/s against the batch per GPU (tile-count quantisation on 256 CUs: 64 pairs = 400 tiles of 256 rows at 40x40)
     X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
     for b in 64 80 48 96 64 80; do timeout 300 python bench.py $X --batch $b > $O/bench_b$b.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/bench_b$b.json'));print('batch $b', d['value'], d['ms_per_step'], d['roofline']['frac'])" | tee -a $O/summary.txt; done ;;
+  inflight)    # forwards in flight x intra-forward stream overlap
+    X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
+    for cfgline in "--in-flight 2" "--in-flight 2 --no-overlap" "--in-flight 3 --no-overlap" "--in-flight 4 --no-overlap" "--in-flight 2"; do
+      timeout 400 python bench.py $X $cfgline > $O/b.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/b.json'));print('$cfgline', d['value'], d['ms_per_step'], d.get('single_in_flight'))" | tee -a $O/summary.txt; done ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
