@@ -166,3 +166,24 @@ def test_hip_nms_score_ties_overflowing_a_chunk(dev):
     dets, counts = batched_nms(p.to(dev), 0.25, 0.45)
     got = dets[0, :int(counts[0])].cpu()
     assert want.shape[0] == 250 and got.shape == want.shape and torch.equal(got, want)
+
+
+@pytest.mark.gpu
+def test_hip_nms_first_chunk_settles_a_crowded_image_and_batches_mix(dev):
+    """Round-3 path (filter -> select + sort -> suppression bit matrix -> one-wave scan): 6000 candidates of which the best
+    2048 already yield max_det survivors (no continuation), in one batch with a sparse image (< 2048 candidates: the chunk is
+    everything) and an empty one; every image bit-equal to the oracle."""
+    from msod_amd.utils.general import batched_nms
+    crowded = _random_pred(6000, 3, 11, spread=3000.0)
+    sparse = _random_pred(6000, 3, 12, spread=500.0)
+    sparse[0, 200:, 4] = 0.0                                   # 200 candidates: fewer than max_det survivors
+    empty = torch.zeros_like(crowded)
+    batch = torch.cat([crowded, sparse, empty, crowded.flip(1)], 0)
+    dets, counts = batched_nms(batch.to(dev), 0.25, 0.45)
+    torch.cuda.synchronize()
+    for b in range(4):
+        want = nms_oracle.non_max_suppression(batch[b:b + 1], 0.25, 0.45)[0]
+        got = dets[b, :int(counts[b])].cpu()
+        assert got.shape == want.shape and torch.equal(got, want), b
+    assert int(counts[0]) == 300 and 0 < int(counts[1]) < 300 and int(counts[2]) == 0
+    assert torch.equal(dets[0, :300].cpu()[:, 4], dets[3, :300].cpu()[:, 4])      # row order of the input does not matter

@@ -32,6 +32,18 @@ case $JOB in
     X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
     for cfgline in "--in-flight 2" "--in-flight 2 --no-overlap" "--in-flight 3 --no-overlap" "--in-flight 4 --no-overlap" "--in-flight 2"; do
       timeout 400 python bench.py $X $cfgline > $O/b.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/b.json'));print('$cfgline', d['value'], d['ms_per_step'], d.get('single_in_flight'))" | tee -a $O/summary.txt; done ;;
+  nms)         # NMS tests + timing on the bench workload
+    timeout 900 python -m pytest tests/test_nms.py tests/test_letterbox.py -q -m gpu -x > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -3 $O/tests.log
+    timeout 600 python tools/nms_bench.py > $O/nms_bench.log 2>&1; echo "bench rc=$?" | tee -a $O/summary.txt; cat $O/nms_bench.log | tail -4; cp gpurun_out/nms_bench.json $O/
+    timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof --output-format csv -- python tools/nms_bench.py > $O/prof.log 2>&1
+    python - <<PY
+import csv, glob
+f = glob.glob("$O/prof/*/*kernel_stats.csv")[0]
+for r in csv.DictReader(open(f)):
+    if "nms" in r["Name"]:
+        print(r["Name"][:40], r["Calls"], r["AverageNs"], r["TotalDurationNs"])
+PY
+    rm -rf $O/prof ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
