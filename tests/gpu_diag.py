@@ -69,6 +69,36 @@ def main():
         out.append(rec)
         del model
         torch.cuda.empty_cache()
+    # the reference's OWN bf16 forward (tests/golden/lowp_ref.pt, recorded in the build container) next to the HIP bf16 / fp16 forward
+    from msod_amd.utils.seeded import default_init_state_dict
+    lowp_ref = torch.load(os.path.join(ROOT, "tests", "golden", "lowp_ref.pt"), weights_only=False)
+    flat = lambda rs: torch.cat([r.float().cpu().reshape(-1) for r in rs])     # noqa: E731
+    for name, rec0 in lowp_ref.items():
+        c = rec0["case"]
+        cfg = named_config(c["cfg"])
+        model = Model(cfg)
+        model.load_state_dict((default_init_state_dict if c["dinit"] else seeded_state_dict)(model.state_dict(), c["seed"]))
+        if c["fused"]:
+            model.fuse()
+        rgb, ir = seeded_inputs(c["batch"], c["height"], c["width"], c["seed"])
+        want = flat(rec0["raw"]) if c["dinit"] else flat(torch.load(os.path.join(ROOT, "tests", "golden", name + ".pt"), weights_only=False)["raw"])
+        ref16 = flat(rec0["raw_bf16"])
+        rec = {"lowp_case": name, "weights": "reference-constructor distributions" if c["dinit"] else "seeded (lively)",
+               "reference_bf16_autocast": {"sigmoid_max_abs": (ref16.sigmoid() - want.sigmoid()).abs().max().item(),
+                                           "rms_over_std": ((ref16 - want).pow(2).mean().sqrt() / want.std()).item()}}
+        model = model.cuda()
+        for dtype in (torch.bfloat16, torch.float16, torch.float32):
+            model.set_compute_dtype(dtype)
+            with torch.no_grad():
+                _, raw = model(rgb.cuda(), ir.cuda())
+            got = flat(raw)
+            rec[f"hip_{str(dtype).split('.')[-1]}"] = {"sigmoid_max_abs": (got.sigmoid() - want.sigmoid()).abs().max().item(),
+                                                      "raw_max_abs": (got - want).abs().max().item(),
+                                                      "rms_over_std": ((got - want).pow(2).mean().sqrt() / want.std()).item()}
+        print(json.dumps(rec), flush=True)
+        out.append(rec)
+        del model
+        torch.cuda.empty_cache()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "diag.json"), "w") as fh:
         json.dump(out, fh, indent=1)

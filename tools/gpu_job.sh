@@ -30,7 +30,7 @@ case $JOB in
     for b in 64 80 48 96 64 80; do timeout 300 python bench.py $X --batch $b > $O/bench_b$b.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/bench_b$b.json'));print('batch $b', d['value'], d['ms_per_step'], d['roofline']['frac'])" | tee -a $O/summary.txt; done ;;
   inflight)    # forwards in flight x intra-forward stream overlap
     X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
-    for cfgline in "--in-flight 2" "--in-flight 2 --no-overlap" "--in-flight 3 --no-overlap" "--in-flight 4 --no-overlap" "--in-flight 2"; do
+    for cfgline in "--in-flight 2" "--in-flight 3" "--in-flight 3 --no-overlap" "--in-flight 4" "--in-flight 2" "--in-flight 3"; do
       timeout 400 python bench.py $X $cfgline > $O/b.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/b.json'));print('$cfgline', d['value'], d['ms_per_step'], d.get('single_in_flight'))" | tee -a $O/summary.txt; done ;;
   nms)         # NMS tests + timing on the bench workload
     timeout 900 python -m pytest tests/test_nms.py tests/test_letterbox.py -q -m gpu -x > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -3 $O/tests.log
@@ -44,6 +44,8 @@ for r in csv.DictReader(open(f)):
         print(r["Name"][:40], r["Calls"], r["AverageNs"], r["TotalDurationNs"])
 PY
     rm -rf $O/prof ;;
+  diag)        # parity diagnostics (measured errors per configuration / precision, incl. vs the reference's own bf16 forward)
+    timeout 900 python tests/gpu_diag.py > $O/diag.log 2>&1; echo "diag rc=$?" | tee $O/summary.txt; cp gpurun_out/diag.json $O/diag.json; grep lowp_case $O/diag.log | cut -c1-400 ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
