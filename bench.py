@@ -94,10 +94,8 @@ def traffic_from_profile(args, n_launch, abytes):
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh ->
     profiles/*_traffic.json: FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, summed
     over the conv_gemm family of one forward).  Only reported for the configuration it was collected on."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (3, 2, 1)) if os.path.exists(q)), None)
+    if path is None:
         return None
     t = json.load(open(path))
     if (t.get("config"), t.get("batch"), t.get("size"), t.get("dtype")) != (args.config, args.batch, args.size, args.dtype):
@@ -324,8 +322,10 @@ def main():
         with ClockSampler() as clk, torch.no_grad():
             el_s = D.timed_steps(step_fn, args.sustained_steps, 2, sync=torch.cuda.synchronize)
         sustained = {"steps": args.sustained_steps, "seconds": round(el_s, 3), "value": round(args.batch * args.sustained_steps / el_s, 2),
-                     "unit": "image-pairs/sec", "ms_per_step": round(el_s / args.sustained_steps * 1e3, 3), "sclk_sysfs_level_mhz": clk.mean_mhz,
-                     "sclk_samples": len(clk.samples)}
+                     "unit": "image-pairs/sec", "ms_per_step": round(el_s / args.sustained_steps * 1e3, 3),
+                     # amdgpu sysfs pp_dpm_sclk level while the leg ran; only reported when it is a plausible shader clock (the file
+                     # holds a power-state table on some driver versions)
+                     "sclk_sysfs_level_mhz": clk.mean_mhz if (clk.mean_mhz or 0) > 500 else None}
         log(f"sustained leg: {sustained}")
 
     if rank == 0:

@@ -46,6 +46,9 @@ PY
     rm -rf $O/prof ;;
   diag)        # parity diagnostics (measured errors per configuration / precision, incl. vs the reference's own bf16 forward)
     timeout 900 python tests/gpu_diag.py > $O/diag.log 2>&1; echo "diag rc=$?" | tee $O/summary.txt; cp gpurun_out/diag.json $O/diag.json; grep lowp_case $O/diag.log | cut -c1-400 ;;
+  prof1)       # rocprofv3 kernel stats of the single-stream, one-forward-in-flight run (per-kernel durations are meaningful)
+    timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof1 --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f16-leg --no-overlap --in-flight 1 --sustained-steps 0 --no-parity > $O/prof1.log 2>&1; echo "prof single-stream rc=$?" | tee $O/summary.txt
+    cp $(ls $O/prof1/*/*kernel_stats.csv | head -1) $O/bench_bs64_kernel_stats.csv; rm -rf $O/prof1; tail -2 $O/prof1.log | cut -c1-300 ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
@@ -55,7 +58,7 @@ PY
     rm -rf $O/traffic; cp $O/traffic.json profiles/r03_traffic.json
     timeout 900 python bench.py > $O/bench_bs64.json 2> $O/bench.log; echo "bench rc=$?" | tee -a $O/summary.txt
     cp gpurun_out/bench_families.json $O/gemm_families_cfg3.json
-    timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof1 --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f16-leg --no-overlap --sustained-steps 0 --no-parity > $O/prof1.log 2>&1; echo "prof single-stream rc=$?" | tee -a $O/summary.txt
+    timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof1 --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f16-leg --no-overlap --in-flight 1 --sustained-steps 0 --no-parity > $O/prof1.log 2>&1; echo "prof single-stream rc=$?" | tee -a $O/summary.txt
     cp $(ls $O/prof1/*/*kernel_stats.csv | head -1) $O/bench_bs64_kernel_stats.csv; rm -rf $O/prof1
     timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof2 --output-format csv -- python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity > $O/prof2.log 2>&1; echo "prof two-stream rc=$?" | tee -a $O/summary.txt
     cp $(ls $O/prof2/*/*kernel_stats.csv | head -1) $O/bench_bs64_kernel_stats_two_streams_40steps.csv; rm -rf $O/prof2

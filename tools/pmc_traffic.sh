@@ -7,7 +7,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d "$OUT/$c" --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f16-leg --no-graph "$@" > "$OUT/$c.log" 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d "$OUT/$c" --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f16-leg --no-graph --sustained-steps 0 --no-parity "$@" > "$OUT/$c.log" 2>&1
   echo "$c rc=$?"
 done
 rm -rf "$OUT"/*/*/*.db
