@@ -227,7 +227,8 @@ int cft_dropout(void* x, long n, float p, unsigned long long seed, int dtype, vo
  * device array of no-5 bytes, non-zero = class kept, :505-506; NULL = all classes), xywh -> xyxy, the max_nms
  * pre-truncation to the highest confidences (:469,:515-516; 0 = off), per-class greedy NMS (class offset
  * 4096 px unless agnostic) with IoU > iou_thres suppression, at most max_det detections.
- *   pred    : float [B, rows, no]            dets : float [B, max_det, 6] (x1,y1,x2,y2,conf,cls), first counts[b] rows valid
+ *   pred    : float [B, rows, no]            dets : float [B, max_det, 6] (x1,y1,x2,y2,conf,cls), first counts[b] rows valid,
+ *                                                   the others zeroed
  *   scratch : >= B * round_up(rows * (multi_label ? no-5 : 1), 4) * 32 bytes of device memory, 16-byte aligned
  */
 int cft_nms(const float* pred, int B, int rows, int no, float conf_thres, float iou_thres,

@@ -345,6 +345,12 @@ extern "C" int cft_nms(const float* pred, int B, int rows, int no, float conf_th
   const long cap_al = (cap + 3) & ~3L;
   CFT_REQUIRE(cap < (1L << 30) && scratch_bytes >= (long)B * cap_al * 32L, "cft_nms: scratch too small (need B * round_up(rows*(multi_label?nc:1), 4) * 32 bytes)");
   CFT_REQUIRE(((size_t)scratch & 15) == 0, "cft_nms: scratch must be 16-byte aligned");
+  // rows of `dets` beyond counts[b] are zero (the kernel writes only what it keeps): cleared here, on the stream, so that callers need no
+  // fill kernel of their own
+  if (hipMemsetAsync(dets, 0, (size_t)B * max_det * 6 * sizeof(float), as_stream(stream)) != hipSuccess) {
+    cft_set_error("cft_nms: hipMemsetAsync failed");
+    return CFT_EINVAL;
+  }
   hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), 0, as_stream(stream), pred, rows, no, conf_thres, iou_thres, agnostic, multi_label,
                      class_allow, max_det, max_nms, (int)cap, (unsigned char*)scratch, dets, counts);
   return cft_check_launch("nms_kernel");

@@ -35,8 +35,8 @@ def batched_nms(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnos
     multi_label = bool(multi_label) and nc > 1            # reference :472
     cap = rows * (nc if multi_label else 1)
     scratch = torch.empty((B * ((cap + 3) // 4 * 4) * 32,), dtype=torch.uint8, device=prediction.device)
-    dets = torch.zeros((B, max_det, 6), dtype=torch.float32, device=prediction.device)
-    counts = torch.zeros((B,), dtype=torch.int32, device=prediction.device)
+    dets = torch.empty((B, max_det, 6), dtype=torch.float32, device=prediction.device)     # cft_nms zeroes the unused rows itself
+    counts = torch.empty((B,), dtype=torch.int32, device=prediction.device)                 # and always writes every count
     if isinstance(classes, torch.Tensor) and classes.dtype == torch.uint8 and classes.numel() == nc and classes.is_cuda \
             and classes.device == prediction.device and classes.is_contiguous():
         allow = classes                       # a ready-made [nc] allow-table on the device (the kernel indexes it by class id)

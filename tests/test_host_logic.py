@@ -258,3 +258,23 @@ print("STRICT-FORM-OK")
 """
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True)
     assert r.returncode == 0 and "STRICT-FORM-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_bench_parity_check_flags_a_wrong_batch():
+    """bench.py's `parity_at_bench_shape`: green for outputs at the reference-style bf16 error level, red for a forward that is off
+    (wrong weights / a broken kernel) and red for a bf16 result that is much worse than the reference's own bf16 - the run then exits 3."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    g = torch.Generator().manual_seed(0)
+    want = [torch.randn(4, 3, 8, 8, 8, generator=g), torch.randn(4, 3, 4, 4, 8, generator=g)]
+    noise = lambda s: [w + s * torch.randn(w.shape, generator=g) for w in want]      # noqa: E731
+    ref16 = [r[:2] for r in noise(0.02)]
+    ok = bench.parity_at_bench_shape("bf16", noise(0.02), want, ref16, 2)
+    assert ok["ok"] and ok["pairs"] == 4 and ok["vs_reference_style_bf16"]["ok"]
+    assert not bench.parity_at_bench_shape("bf16", noise(0.5), want, ref16, 2)["ok"]             # absolute bound
+    worse = bench.parity_at_bench_shape("bf16", noise(0.06), want, ref16, 2)                     # inside 2.5e-2? no - and 3x the reference level
+    assert not worse["ok"]
+    assert bench.parity_at_bench_shape("f16", noise(0.002), want)["ok"] and not bench.parity_at_bench_shape("f16", noise(0.1), want)["ok"]
+    assert bench.parity_at_bench_shape("f32", noise(1e-5), want)["ok"] and not bench.parity_at_bench_shape("f32", noise(0.01), want)["ok"]

@@ -1,8 +1,7 @@
-"""Time cft_bottleneck against the two cft_conv2d launches it replaces, and its ablation probes.
+"""Time cft_bottleneck against the two cft_conv2d launches it replaces, and (probe build only: tools/build_probes.sh) its ablation probes.
     python tools/bneck_bench.py [C] [variants]      C = 64 (160x160 stage) or 128 (80x80 stage), batch 64
-64 channels: 0 = ring kernel (two per CU), 9640 = weights-resident kernel; 9601 / 9602 / 9604 / 9608 = ring kernel without W1-stage MFMAs /
-3x3 MFMAs / epilogue / weight DMA; 901 = resident kernel without phase 1, 902 = no phase-2 MFMAs, 904 = no epilogue, 907 = none of them.
-128 channels: 901 = no t-patch MFMAs, 902 = no 3x3 MFMAs, 904 = no epilogue, 908 = no weight DMA."""
+variant 0 = the shipped kernel.  Probe build, 64 channels: 9601 / 9602 / 9604 / 9608 = without W1-stage MFMAs / 3x3 MFMAs / epilogue /
+weight DMA; 128 channels: 9201 / 9202 / 9204 / 9208 = the same, 9456 = no x requests, 9712 = no SiLU."""
 import json
 import os
 import sys
@@ -51,7 +50,7 @@ def main():
         us = timeit(lambda: ops.conv2d(ops.conv2d(x, pk1, 1, out=t), pk2, 1, residual=x, out=out))
         res["two_launches_us"] = round(us, 1)
         print(f"two launches: {us:.1f} us  ({flops / us / 1e6:.0f} TFLOP/s)")
-    for v in (only or ((9640, 0, 9640, 0, 9601, 9602, 9604, 9608) if C == 64 else (0, 901, 902, 904, 908))):
+    for v in (only or ((0, 9601, 9602, 9604, 9608) if C == 64 else (0, 9201, 9202, 9204, 9208, 9456, 9712))):
         lib.cft_set_conv_variant(v)
         us = timeit(lambda: ops.bottleneck(x, pk1, pk2, True, out=out))
         res[f"fused_v{v}_us"] = round(us, 1)
