@@ -288,9 +288,11 @@ def main():
         # stream t % K: consecutive steps are independent batches and overlap on the GPU (distributed.ForwardPipeline) - the
         # low-occupancy stretches of one forward (CFT blocks with M = 8192, the single-stream head) run under the other's
         # backbone convolutions.  --in-flight 1 = one forward at a time (also reported as "single_in_flight").
+        stream_probe_ms = None
         if k_fly > 1:
-            pipe = D.ForwardPipeline([(lambda c=c: c.replay_static()[0]) for c in caps],
-                                     [torch.cuda.Stream(device=dev) for _ in caps], gather)
+            runners = [(lambda c=c: c.replay_static()[0]) for c in caps]
+            fly_streams, stream_probe_ms = D.ForwardPipeline.pick_streams(runners, dev)      # untimed set-up: the stream group that overlaps best
+            pipe = D.ForwardPipeline(runners, fly_streams, gather)
             step_fn = pipe.step
         else:
             step_fn = lambda: step_seq()[0]   # noqa: E731
@@ -364,6 +366,7 @@ def main():
                                    f"{args.size}x{args.size}, {args.batch} pairs/GPU, BN folded, pre-NMS detections",
                        "pairs_per_gpu": args.batch, "image_size": args.size, "parallelism": f"batch-shard x{world}",
                        "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap, "forwards_in_flight": k_fly,
+                       **({"stream_group_probe_ms_per_step": stream_probe_ms} if stream_probe_ms else {}),
                        **({"conv_variant": args.conv_variant} if args.conv_variant else {})},
             "sustained": sustained, "single_in_flight": single, "multi_gpu_selfcheck": selfcheck,
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear family; incl. the dedicated Focus kernel and the fused 64- / 128-channel Bottleneck kernels: 2 + 27 launches of the cfg3 forward)",
@@ -392,7 +395,7 @@ def main():
                     c.ir.copy_(ir)
                 cap16 = caps16[0]
                 if k_fly > 1:
-                    fn16 = D.ForwardPipeline([(lambda c=c: c.replay_static()[0]) for c in caps16], [torch.cuda.Stream(device=dev) for _ in caps16]).step
+                    fn16 = D.ForwardPipeline([(lambda c=c: c.replay_static()[0]) for c in caps16], fly_streams).step
                 else:
                     fn16 = lambda: cap16.replay_static()[0]   # noqa: E731
                 torch.cuda.synchronize()

@@ -243,6 +243,28 @@ class ForwardPipeline:
         if streams is not None and len(streams) != len(self.runners):
             raise ValueError("one stream per runner")
 
+    @staticmethod
+    def pick_streams(runners, device, groups=4, probe_steps=6):
+        """HIP maps streams onto a few hardware queues, and a captured forward brings internal branch streams of its own: which
+        streams the forwards in flight are replayed on changes the steady-state rate by up to 8 % (two attractors, measured:
+        profiles/r03_forwards_in_flight.txt).  This draws ``groups`` candidate groups of K streams, times ``probe_steps`` steps per
+        forward on each and returns the fastest group (plus the measured table)."""
+        k = len(runners)
+        cands = [[torch.cuda.Stream(device=device) for _ in range(k)] for _ in range(groups)]
+        table = []
+        for streams in cands:
+            pipe = ForwardPipeline(runners, streams)
+            for _ in range(k):
+                pipe.step()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(probe_steps * k):
+                pipe.step()
+            torch.cuda.synchronize(device)
+            table.append((time.perf_counter() - t0) / (probe_steps * k))
+        best = min(range(groups), key=lambda i: table[i])
+        return cands[best], [round(t * 1e3, 3) for t in table]
+
     def step(self):
         import contextlib
         i = self.tick % len(self.runners)
