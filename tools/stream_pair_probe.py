@@ -1,5 +1,7 @@
-"""Experiment: two forwards in flight - does a phase offset between them (one in its backbone while the other is in its CFT blocks /
-head) or a stream priority change the steady-state rate?  (run on the GPU box)"""
+"""Two forwards in flight: ms per step for every ordered pair of 8 torch pool streams (and the default stream).  HIP maps streams onto
+a few hardware queues (pool index mod 4 here) and a captured forward brings internal branch streams of its own: pairs on queues
+(0,1), (1,0), (3,1) run at 18.5-18.7 ms, every other pair at 19.6-20.3 ms (profiles/r03_forwards_in_flight.txt).  This is why
+distributed.ForwardPipeline.pick_streams() probes a few stream groups before the timed region.  (run on the GPU box)"""
 import json
 import os
 import sys
