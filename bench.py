@@ -395,7 +395,8 @@ def main():
                     c.ir.copy_(ir)
                 cap16 = caps16[0]
                 if k_fly > 1:
-                    fn16 = D.ForwardPipeline([(lambda c=c: c.replay_static()[0]) for c in caps16], fly_streams).step
+                    run16 = [(lambda c=c: c.replay_static()[0]) for c in caps16]
+                    fn16 = D.ForwardPipeline(run16, D.ForwardPipeline.pick_streams(run16, dev)[0]).step    # (new graphs: probe the stream groups again)
                 else:
                     fn16 = lambda: cap16.replay_static()[0]   # noqa: E731
                 torch.cuda.synchronize()
