@@ -362,6 +362,34 @@ def test_graph_replay_is_bit_identical_to_eager(dev, dtype):
     model.release_graphs()
 
 
+def test_two_forwards_in_flight_do_not_interfere(dev):
+    """bench.py's step mode (distributed.ForwardPipeline): two captured graphs with their OWN static buffers and DIFFERENT inputs,
+    replayed round-robin on two streams so that they overlap on the GPU - every replay must reproduce the eager result of its
+    own input bit for bit (no shared scratch between forwards in flight)."""
+    from msod_amd import distributed as D
+    from msod_amd.graph import CapturedForward
+    from msod_amd.utils.seeded import seeded_inputs
+    g, cfg, model, rgb, ir = load_case([p for p in GOLDEN if p.endswith("s_x3_320.pt")][0])
+    model = model.to(dev).set_compute_dtype(torch.bfloat16)
+    ins = [seeded_inputs(4, 320, 320, s) for s in (71, 72)]
+    with torch.no_grad():
+        want = [model.forward_once(a.to(dev), b.to(dev))[0].clone() for a, b in ins]
+        caps = [CapturedForward(model, 4, 320, 320) for _ in ins]
+        for c, (a, b) in zip(caps, ins):
+            c.rgb.copy_(a)
+            c.ir.copy_(b)
+        runners = [(lambda c=c: c.replay_static()[0]) for c in caps]
+        streams, table = D.ForwardPipeline.pick_streams(runners, dev, groups=2, probe_steps=2)
+        pipe = D.ForwardPipeline(runners, streams)
+        assert len(table) == 2 and all(t > 0 for t in table)
+        for _ in range(12):
+            pipe.step()
+        torch.cuda.synchronize()
+    assert not torch.equal(want[0], want[1])
+    for c, w in zip(caps, want):
+        assert torch.equal(c.pred, w)
+
+
 def test_captured_graph_is_dropped_when_weights_change(dev):
     """a captured graph replays the packed weights of capture time; in-place weight updates,
     load_state_dict and .to()/.half() must not return detections of the old weights."""

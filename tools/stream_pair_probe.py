@@ -52,7 +52,19 @@ def main():
             row.append(round(run((pool[i], pool[j])), 2) if i != j else None)
         print(i, row, flush=True)
         out.append(row)
+    def run1(stream, steps=12):
+        with torch.cuda.stream(stream):
+            caps[0].graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(steps):
+            with torch.cuda.stream(stream):
+                caps[0].graph.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
     default = torch.cuda.current_stream(dev)
+    print("one forward in flight: default", round(run1(default), 2), "pool[j]", [round(run1(pool[j]), 2) for j in range(8)], flush=True)
     print("default+pool[j]", [round(run((default, pool[j])), 2) for j in range(8)], flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "stream_pair_matrix.json"), "w"), indent=1)
