@@ -245,6 +245,7 @@ def main():
     ap.add_argument("--conv-variant", type=int, default=0, help="A/B runs: cft_set_conv_variant() for the whole process (0 = automatic)")
     args = ap.parse_args()
 
+    exit_code = 0
     rank, world, local = D.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -440,12 +441,11 @@ def main():
         print(json.dumps(line), flush=True)
         if not ok:
             log("PARITY FAILURE at the benchmarked shape - see parity_at_bench_shape in the line above")
-            if world > 1:
-                torch.distributed.destroy_process_group()
-            sys.exit(3)
+            exit_code = 3
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    sys.exit(exit_code)
 
 
 if __name__ == "__main__":
