@@ -49,6 +49,12 @@ PY
   prof1)       # rocprofv3 kernel stats of the single-stream, one-forward-in-flight run (per-kernel durations are meaningful)
     timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof1 --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f16-leg --no-overlap --in-flight 1 --sustained-steps 0 --no-parity > $O/prof1.log 2>&1; echo "prof single-stream rc=$?" | tee $O/summary.txt
     cp $(ls $O/prof1/*/*kernel_stats.csv | head -1) $O/bench_bs64_kernel_stats.csv; rm -rf $O/prof1; tail -2 $O/prof1.log | cut -c1-300 ;;
+  pmc)         # PMC counters of the 16-wave GEMM kernel on 3x3 256->256 @40 (+res), generic (900) and uniform-K-walk (0) address path
+    for v in 900 0; do
+      bash tools/pmc.sh $O/v$v -- python tools/gemm_bench.py --variants $v --iters 10 --only "bneck 3x3 256->256" --out $JOB/g$v.json > $O/pmc_v$v.log 2>&1
+      python tools/pmc_summary.py $O/v$v conv_gemm > $O/pmc_3x3_256ch_40x40_variant$v.txt; rm -rf $O/v$v
+      head -30 $O/pmc_3x3_256ch_40x40_variant$v.txt
+    done ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
