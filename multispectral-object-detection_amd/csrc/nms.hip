@@ -94,8 +94,8 @@ __global__ void __launch_bounds__(1024) nms_kernel(const float* __restrict__ pre
   __shared__ unsigned s_prefix, s_want;
   __shared__ float s_score[16];
   __shared__ int s_key[16], s_idx[16];
-  __shared__ float p_score[32];           // wave partials of the LDS-chunk rounds, double-buffered by round parity
-  __shared__ int p_key[32], p_idx[32];
+  __shared__ int c_org[NMS_CHUNK];        // sorted position -> chunk slot
+  __shared__ unsigned d_lo[64], d_hi[64]; // in-block suppression bits of the 64 candidates being resolved
   __shared__ float s_box[4];
   __shared__ float c_x1[NMS_CHUNK], c_y1[NMS_CHUNK], c_x2[NMS_CHUNK], c_y2[NMS_CHUNK], c_sc[NMS_CHUNK];
   __shared__ int c_idx[NMS_CHUNK], c_key[NMS_CHUNK];   // c_x1.. hold the class-shifted boxes the IoU runs on; c_idx -> the exact box
@@ -214,47 +214,113 @@ __global__ void __launch_bounds__(1024) nms_kernel(const float* __restrict__ pre
         }
         __syncthreads();
       }
-      // greedy rounds on the LDS chunk.  ONE barrier per round (round 2 had three and a serial 16-way reduce by thread 0:
-      // 2.9 us per round, 0.87 of the 1.0 ms of a crowded batch): wave partials go to a double-buffered LDS array, EVERY
-      // thread reduces the 16 partials itself after the barrier, so all threads know the round's winner; its owner thread
-      // retires it, thread 0 emits it, and the winner's box is read straight from the chunk arrays.
-      int bi = -1;                          // previous round's winner (chunk slot)
-      float bx1 = 0.f, by1 = 0.f, bx2 = 0.f, by2 = 0.f;
-      for (int round = 0;; ++round) {
-        float ls = -1.f;
-        int lk = 0x7fffffff, li = -1;
-        for (int j = tid; j < m; j += 1024) {
-          const float sc = c_sc[j];
-          if (sc < 0.f) continue;
-          if (j == bi) { c_sc[j] = -1.f; continue; }                 // the owner retires the previous winner
-          if (bi >= 0 && iou_exceeds(c_x1[j], c_y1[j], c_x2[j], c_y2[j], bx1, by1, bx2, by2, iou_thres)) { c_sc[j] = -1.f; continue; }
-          const int ky = c_key[j];
-          if (better(sc, ky, ls, lk)) { ls = sc; lk = ky; li = j; }
+      // Greedy selection on the LDS chunk WITHOUT one workgroup-wide arg-max per detection (round 2: 2.9 us per detection):
+      //   1. the chunk is sorted once by (score descending, key ascending) - the order greedy NMS visits candidates in;
+      //   2. it is walked in BLOCKS of 64 sorted candidates: all threads compute the block's 64 x 64 suppression bits, wave 0
+      //      resolves the block sequentially in registers (next live candidate is kept, the candidates it suppresses
+      //      are cleared), then all threads clear the LATER candidates that the block's new detections suppress.
+      // Every IoU test is the same call as before (later candidate against the kept box); exact.
+      int P = 64;
+      while (P < m) P <<= 1;                                     // bitonic size
+      for (int j = tid; j < P; j += 1024) {
+        c_org[j] = j;
+        if (j >= m) { c_sc[j] = -1.f; c_key[j] = 0x7fffffff; }
+      }
+      __syncthreads();
+      for (int k = 2; k <= P; k <<= 1) {
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+          for (int i = tid; i < P; i += 1024) {
+            const int l = i ^ jj;
+            if (l > i) {
+              const bool first_half = (i & k) == 0;             // "better first" in the first half of each 2k run, reversed in the second
+              const float si = c_sc[i], sl = c_sc[l];
+              const int ki = c_key[i], kl = c_key[l];
+              if (better(sl, kl, si, ki) == first_half) {
+                c_sc[i] = sl; c_sc[l] = si; c_key[i] = kl; c_key[l] = ki;
+                const int t = c_org[i]; c_org[i] = c_org[l]; c_org[l] = t;
+              }
+            }
+          }
+          __syncthreads();
         }
+      }
+      // live candidates (score >= 0) now sit in front, best first
+      if (tid == 0) s_m = 0;
+      __syncthreads();
+      {
+        int cnt = 0;
+        for (int j = tid; j < m; j += 1024) cnt += c_sc[j] >= 0.f ? 1 : 0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const float s2 = __shfl_xor(ls, o);
-          const int k2 = __shfl_xor(lk, o), i2 = __shfl_xor(li, o);
-          if (better(s2, k2, ls, lk)) { ls = s2; lk = k2; li = i2; }
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (lane == 0 && cnt) atomicAdd(&s_m, cnt);
+      }
+      __syncthreads();
+      const int L = s_m;
+      for (int blk = 0; blk * 64 < L; ++blk) {
+        const int p0 = blk * 64;
+        // (a) in-block suppression bits: thread (row i = tid >> 4, columns 4 (tid & 15) .. + 3): bit j of row i = candidate j > i of the
+        //     block is suppressed by candidate i
+        {
+          const int i = tid >> 4, jb = (tid & 15) * 4;
+          unsigned lo = 0u, hiw = 0u;
+          if (p0 + i < L) {
+            const int oi = c_org[p0 + i];
+            const float ax1 = c_x1[oi], ay1 = c_y1[oi], ax2 = c_x2[oi], ay2 = c_y2[oi];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int j = jb + q;
+              if (j > i && p0 + j < L) {
+                const int oj = c_org[p0 + j];
+                if (iou_exceeds(c_x1[oj], c_y1[oj], c_x2[oj], c_y2[oj], ax1, ay1, ax2, ay2, iou_thres)) {
+                  if (j < 32) lo |= 1u << j; else hiw |= 1u << (j - 32);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) { lo |= __shfl_xor(lo, o); hiw |= __shfl_xor(hiw, o); }    // OR over the 16 lanes of the row
+          if ((tid & 15) == 0) { d_lo[i] = lo; d_hi[i] = hiw; }
         }
-        const int pb = (round & 1) * 16;
-        if (lane == 0) { p_score[pb + wave] = ls; p_key[pb + wave] = lk; p_idx[pb + wave] = li; }
         __syncthreads();
-        float bs = p_score[pb]; int bk = p_key[pb]; bi = p_idx[pb];
-#pragma unroll
-        for (int w = 1; w < 16; ++w) {
-          const float s2 = p_score[pb + w];
-          const int k2 = p_key[pb + w];
-          if (better(s2, k2, bs, bk)) { bs = s2; bk = k2; bi = p_idx[pb + w]; }
+        // (b) wave 0 resolves the block
+        if (wave == 0) {
+          const bool live = p0 + lane < L && c_sc[p0 + lane] >= 0.f;
+          unsigned long long alive = __ballot(live), keepbits = 0ull;
+          const unsigned long long mydiag = ((unsigned long long)d_hi[lane] << 32) | d_lo[lane];
+          int nk = kept;
+          while (alive != 0ull && nk < max_det) {
+            const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));
+            keepbits |= 1ull << i;
+            ++nk;
+            alive &= ~(1ull << i);
+            const unsigned dl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mydiag, i);
+            const unsigned dh = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mydiag >> 32), i);
+            alive &= ~(((unsigned long long)dh << 32) | dl);
+          }
+          if ((keepbits >> lane) & 1ull) {
+            const int pos = kept + __builtin_popcountll(keepbits & ((1ull << lane) - 1ull));
+            const int o = c_org[p0 + lane];
+            k_src[pos] = c_idx[o]; k_sc[pos] = c_sc[p0 + lane];
+            k_x1[pos] = c_x1[o]; k_y1[pos] = c_y1[o]; k_x2[pos] = c_x2[o]; k_y2[pos] = c_y2[o];
+          }
+          if (lane == 0) s_best = nk;
         }
-        if (bi < 0) break;                  // chunk exhausted (uniform: every thread reduced the same partials)
-        bx1 = c_x1[bi]; by1 = c_y1[bi]; bx2 = c_x2[bi]; by2 = c_y2[bi];
-        if (tid == 0) {       // no global memory access inside a round (a dependent load here cost 2 us per round): the winner is only
-          k_src[kept] = c_idx[bi]; k_sc[kept] = bs;      // recorded; the detections are written by all threads after the last chunk
-          k_x1[kept] = bx1; k_y1[kept] = by1; k_x2[kept] = bx2; k_y2[kept] = by2;
+        __syncthreads();
+        const int kept_new = s_best;
+        if (kept_new == max_det) { kept = kept_new; break; }
+        // (c) the block's new detections suppress later candidates
+        if (kept_new > kept) {
+          for (int pp = p0 + 64 + tid; pp < L; pp += 1024) {
+            if (c_sc[pp] < 0.f) continue;
+            const int o = c_org[pp];
+            const float x1 = c_x1[o], y1 = c_y1[o], x2 = c_x2[o], y2 = c_y2[o];
+            bool dead = false;
+            for (int k = kept; k < kept_new && !dead; ++k) dead = iou_exceeds(x1, y1, x2, y2, k_x1[k], k_y1[k], k_x2[k], k_y2[k], iou_thres);
+            if (dead) c_sc[pp] = -1.f;
+          }
         }
-        ++kept;
-        if (kept == max_det) break;
+        kept = kept_new;
+        __syncthreads();
       }
       kept_lds = kept;
       __syncthreads();
