@@ -8,11 +8,12 @@
 //            only the max_nms highest confidences take part - an 8-bit-per-pass radix select of the max_nms-th
 //            score in LDS, then everything below it is dropped (candidates that TIE with that score all stay;
 //            the reference's unstable argsort leaves their order unspecified);
-//   phase 2  greedy selection: up to max_det rounds of {workgroup arg-max of the live scores, emit it,
-//            kill every live box whose IoU with it exceeds iou_thres}, run on LDS-resident CHUNKS of the
-//            highest remaining scores (see nms_kernel).  Boxes of different classes are separated by the
-//            reference's class offset (cls * 4096) unless agnostic.  This is exactly the order torchvision's
-//            nms produces (descending score) truncated to max_det, without sorting all candidates.
+//   phase 2  greedy selection on LDS-resident CHUNKS of the <= 2048 highest remaining scores (see nms_kernel): a chunk
+//            is sorted once by (score descending, key ascending) and walked in blocks of 64 - in-block suppression
+//            bits by all threads, one wave resolves the block in registers, all threads clear the later candidates
+//            the block's detections suppress (round 2 ran one workgroup-wide arg-max per detection: 2.9 us each).
+//            Boxes of different classes are separated by the reference's class offset (cls * 4096) unless agnostic.
+//            This is exactly the order torchvision's nms produces (descending score) truncated to max_det.
 // Ties between equal scores are broken by the lower (row, class) key, which makes the result deterministic.
 #include "cft_common.h"
 
@@ -80,11 +81,10 @@ __device__ __forceinline__ unsigned nms_radix_select(const float* __restrict__ s
 //   phase 1b  max_nms pre-truncation (radix select of the max_nms-th score);
 //   phase 2   greedy selection in CHUNKS of the highest remaining scores: the next <= 2048 candidates by score are
 //             copied into LDS (a radix select finds the chunk's score threshold; candidates that tie with it all
-//             belong to the chunk), first thinned by the boxes kept so far, then up to max_det rounds of
-//             {workgroup arg-max of the live scores, emit, kill what it suppresses} run entirely on LDS.  Greedy NMS
-//             visits candidates in descending score, so nothing outside the current chunk can precede anything in it;
-//             with max_det = 300 the first chunk almost always suffices and the 25200-row arrays are only read twice.
-//             (A chunk whose score ties overflow the LDS arrays falls back to rounds over global memory.)
+//             belong to the chunk), first thinned by the boxes kept so far, then sorted and walked in blocks of 64
+//             (see below).  Greedy NMS visits candidates in descending score, so nothing outside the current chunk can
+//             precede anything in it; the 25200-row arrays are read two or three times per chunk.
+//             (A chunk whose score ties overflow the LDS arrays falls back to arg-max rounds over global memory.)
 __global__ void __launch_bounds__(1024) nms_kernel(const float* __restrict__ pred, int rows, int no, float conf_thres,
                                                    float iou_thres, int agnostic, int multi_label, const unsigned char* __restrict__ class_allow,
                                                    int max_det, int max_nms, int cap, unsigned char* __restrict__ scratch, float* __restrict__ dets,
