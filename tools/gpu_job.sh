@@ -55,6 +55,13 @@ PY
       python tools/pmc_summary.py $O/v$v conv_gemm > $O/pmc_3x3_256ch_40x40_variant$v.txt; rm -rf $O/v$v
       head -30 $O/pmc_3x3_256ch_40x40_variant$v.txt
     done ;;
+  kg4)         # half-K-step tiles (variants 61 / 62): tests, per-shape A/B against the automatic choice; small-batch in-flight sweep
+    timeout 900 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "alternative_gemm or every_tile" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -3 $O/tests.log
+    timeout 900 python tools/gemm_bench.py --variants 0,61,62 --out $JOB/gemm.json > $O/gemm.log 2>&1; echo "gemm rc=$?" | tee -a $O/summary.txt
+    grep -E "^variant|^best" $O/gemm.log
+    X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
+    for cfgline in "--batch 8 --in-flight 2" "--batch 8 --in-flight 4" "--batch 8 --in-flight 8" "--batch 16 --in-flight 4"; do
+      timeout 400 python bench.py $X $cfgline > $O/b.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/b.json'));print('$cfgline', d['value'], d['ms_per_step'], d.get('single_in_flight',{}).get('value'))" | tee -a $O/summary.txt; done ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
