@@ -55,7 +55,7 @@ PY
       python tools/pmc_summary.py $O/v$v conv_gemm > $O/pmc_3x3_256ch_40x40_variant$v.txt; rm -rf $O/v$v
       head -30 $O/pmc_3x3_256ch_40x40_variant$v.txt
     done ;;
-  kg4)         # half-K-step tiles (variants 61 / 62): tests, per-shape A/B against the automatic choice; small-batch in-flight sweep
+  kg4)         # (needs tools/experimental/r03_half_kstep.patch applied + rebuilt) half-K-step tiles (variants 61 / 62): tests, per-shape A/B against the automatic choice; small-batch in-flight sweep
     timeout 900 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "alternative_gemm or every_tile" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -3 $O/tests.log
     timeout 900 python tools/gemm_bench.py --variants 0,61,62 --out $JOB/gemm.json > $O/gemm.log 2>&1; echo "gemm rc=$?" | tee -a $O/summary.txt
     grep -E "^variant|^best" $O/gemm.log
