@@ -305,7 +305,7 @@ def main():
     assert all(torch.equal(c.pred, pred) for c in caps[1:]), "the graphs in flight disagree"
     log(f"timed region: {elapsed:.3f} s for {args.steps} steps ({k_fly} in flight)")
     local_elapsed = getattr(D.timed_steps, "last_local_elapsed", elapsed)
-    n_par = 0 if args.no_parity else min(args.batch, 2 if args.no_cpu_baseline else 8)
+    n_par = 0 if args.no_parity else min(args.batch, 8 if (world == 1 and not args.no_cpu_baseline) else 2)   # 8 pairs come free with the CPU leg (N = 1)
     with torch.no_grad():
         raw_now = step_seq()[1]
         torch.cuda.synchronize()
