@@ -62,6 +62,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variants", default="1,2,5,9")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--rounds", type=int, default=3, help="timed passes per variant, interleaved over the variants (A B C A B C ...): the median is reported")
+    ap.add_argument("--warm", type=int, default=10, help="untimed launches before every timed pass (a pass that follows idle time runs at boost clocks: "
+                    "the first variant of a back-to-back pair measured up to 10 %% faster on MFMA-bound shapes, profiles/r03_gemm_experiments.md 5d)")
     ap.add_argument("--only", default="")
     ap.add_argument("--out", default="gemm_bench.json")
     ap.add_argument("--dtype", default="bf16")
@@ -88,7 +91,8 @@ def main():
         byts = 2.0 * (B * H * W * Cin + B * Ho * Wo * N * (2 if use_res else 1) + N * k * k * Cin)
         rec = {"shape": name, "gflop": flops / 1e9, "mbytes": byts / 1e6, "count": count, "variants": {}}
         ref = None
-        for v in variants:
+        outs, times = {}, {v: [] for v in variants}
+        for v in variants:                       # correctness pass (and first-touch) per variant
             lib.cft_set_conv_variant(v)
             try:
                 out = ops.conv2d(x, pk, 1, residual=res)
@@ -98,16 +102,31 @@ def main():
                     diff = 0.0
                 else:
                     diff = (out.float() - ref).abs().max().item()
+                outs[v] = (out, diff)
+            except Exception as e:  # noqa: BLE001
+                rec["variants"][v] = {"error": repr(e)[:200]}
+        for _ in range(max(1, args.rounds)):     # timed passes, interleaved over the variants, each behind its own warm-up
+            for v in variants:
+                if v not in outs:
+                    continue
+                lib.cft_set_conv_variant(v)
+                out = outs[v][0]
+                for _ in range(args.warm):
+                    ops.conv2d(x, pk, 1, residual=res, out=out)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.iters):
                     ops.conv2d(x, pk, 1, residual=res, out=out)
                 e1.record()
                 torch.cuda.synchronize()
-                us = e0.elapsed_time(e1) * 1e3 / args.iters
-                rec["variants"][v] = {"us": round(us, 1), "tflops": round(flops / us / 1e6, 1), "tbps": round(byts / us / 1e6, 2), "maxdiff_vs_first": diff}
-            except Exception as e:  # noqa: BLE001
-                rec["variants"][v] = {"error": repr(e)[:200]}
+                times[v].append(e0.elapsed_time(e1) * 1e3 / args.iters)
+        for v in variants:
+            if v in outs:
+                ts = sorted(times[v])
+                us = ts[len(ts) // 2]
+                rec["variants"][v] = {"us": round(us, 1), "tflops": round(flops / us / 1e6, 1), "tbps": round(byts / us / 1e6, 2),
+                                      "maxdiff_vs_first": outs[v][1], "passes_us": [round(t, 1) for t in times[v]]}
+        del outs
         lib.cft_set_conv_variant(0)
         print(json.dumps(rec), flush=True)
         results.append(rec)

@@ -62,6 +62,12 @@ PY
     X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
     for cfgline in "--batch 8 --in-flight 2" "--batch 8 --in-flight 4" "--batch 8 --in-flight 8" "--batch 16 --in-flight 4"; do
       timeout 400 python bench.py $X $cfgline > $O/b.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/b.json'));print('$cfgline', d['value'], d['ms_per_step'], d.get('single_in_flight',{}).get('value'))" | tee -a $O/summary.txt; done ;;
+  persist)     # (needs tools/experimental/r03_persistent_tiles.patch applied + rebuilt) persistent tile loop of the GEMM family (variant 0) against one workgroup per tile (variant 901): tests, per-shape A/B, whole forward A/B
+    timeout 1200 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "conv or gemm or bottleneck or focus or linear or tile" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -3 $O/tests.log
+    timeout 900 python tools/gemm_bench.py --variants 901,0 --out $JOB/gemm.json > $O/gemm.log 2>&1; echo "gemm rc=$?" | tee -a $O/summary.txt
+    grep -E "^variant|^best" $O/gemm.log
+    X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
+    for v in 901 0 901 0; do timeout 300 python bench.py $X --conv-variant $v > $O/bench_v$v.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/bench_v$v.json'));print('variant $v', d['value'], d['ms_per_step'], d['single_in_flight']['value'], d['roofline']['frac'])" | tee -a $O/summary.txt; done ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
