@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--warm", type=int, default=10, help="untimed launches before every timed pass (a pass that follows idle time runs at boost clocks: "
                     "the first variant of a back-to-back pair measured up to 10 %% faster on MFMA-bound shapes, profiles/r03_gemm_experiments.md 5d)")
     ap.add_argument("--only", default="")
+    ap.add_argument("--used", action="store_true", help="only the shapes that occur in the cfg3 forward (count > 0)")
     ap.add_argument("--out", default="gemm_bench.json")
     ap.add_argument("--dtype", default="bf16")
     args = ap.parse_args()
@@ -77,6 +78,8 @@ def main():
     g = torch.Generator().manual_seed(0)
     for name, B, H, W, Cin, N, k, s, use_res, count in SHAPES:
         if args.only and not any(o in name for o in args.only.split('|')):
+            continue
+        if args.used and count == 0:
             continue
         x = ops.new_nhwc(B, H, W, Cin, dtype, dev)
         x.copy_(torch.randn(x.shape, device=dev) )

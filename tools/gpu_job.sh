@@ -68,6 +68,9 @@ PY
     grep -E "^variant|^best" $O/gemm.log
     X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
     for v in 901 0 901 0; do timeout 300 python bench.py $X --conv-variant $v > $O/bench_v$v.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/bench_v$v.json'));print('variant $v', d['value'], d['ms_per_step'], d['single_in_flight']['value'], d['roofline']['frac'])" | tee -a $O/summary.txt; done ;;
+  tiles)       # tile choice re-check with the interleaved, warmed per-shape timing: automatic choice against the forced tile variants
+    timeout 1200 python tools/gemm_bench.py --used --variants ${1:-0,27,60,51,23,33,30,6,63,2} --rounds 3 --out $JOB/gemm.json > $O/gemm.log 2>&1; echo "gemm rc=$?" | tee $O/summary.txt
+    grep -E "^variant|^best" $O/gemm.log ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
