@@ -225,6 +225,69 @@ class ClockSampler:
         return round(sum(self.samples) / len(self.samples), 1) if self.samples else None
 
 
+class ShaderClockProbe:
+    """Shader clock the SIMDs run at while a leg is in flight, read from inside the GPU: every ``period`` seconds a thread
+    launches ``cft_clock_probe`` (one wave, ``spin_us`` of the constant-rate wall clock) on its own stream next to the forward;
+    the kernel returns its s_memtime ticks, its wall-clock ticks and the dependent FMAs it executed.  ``summary()`` gives MHz
+    from ticks / wall time (when s_memtime runs at the shader clock) and, independent of that, the FMA rate relative to a probe
+    taken on the idle GPU (a dependent v_fma_f32 chain costs a fixed number of shader cycles)."""
+
+    def __init__(self, dev, period=0.25, spin_us=200, max_samples=256):
+        import ctypes
+        import threading
+        from msod_amd import _lib
+        self.lib, self.ct = _lib.load(), ctypes
+        self.dev, self.period, self.spin_us, self.max = dev, period, spin_us, max_samples
+        self.buf = torch.zeros((max_samples + 1, 4), dtype=torch.int64, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.khz = ctypes.c_int(0)
+        self.n, self.stop = 0, threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.idle = None
+
+    def _launch(self, slot):
+        st = self.lib.cft_clock_probe(self.buf[slot].data_ptr(), self.spin_us, self.ct.byref(self.khz), self.stream.cuda_stream)
+        return st == 0
+
+    def measure_idle(self):
+        torch.cuda.synchronize(self.dev)
+        time.sleep(0.2)
+        if self._launch(self.max):
+            self.stream.synchronize()
+            self.idle = self.buf[self.max].tolist()
+
+    def _run(self):
+        torch.cuda.set_device(self.dev)
+        while not self.stop.is_set() and self.n < self.max:
+            if self._launch(self.n):
+                self.n += 1
+            self.stop.wait(self.period)
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop.set()
+        self.thread.join(5)
+        self.stream.synchronize()
+
+    def summary(self):
+        rows = [r for r in self.buf[:self.n].tolist() if r[1] > 0]
+        if not rows or self.khz.value <= 0:
+            return None
+        wall_mhz = self.khz.value / 1e3
+        mhz = sorted(r[0] / r[1] * wall_mhz for r in rows)
+        fma = sorted(r[2] / r[1] * wall_mhz for r in rows)          # dependent FMAs per microsecond
+        out = {"samples": len(rows), "s_memtime_mhz": {"median": round(mhz[len(mhz) // 2], 1), "min": round(mhz[0], 1), "max": round(mhz[-1], 1)},
+               "dependent_fma_per_us": {"median": round(fma[len(fma) // 2], 1), "min": round(fma[0], 1), "max": round(fma[-1], 1)},
+               "method": "cft_clock_probe: a one-wave kernel on a side stream every 0.25 s (s_memtime / s_memrealtime ticks and a dependent v_fma_f32 chain over 200 us)"}
+        if self.idle and self.idle[1] > 0:
+            out["idle_gpu"] = {"s_memtime_mhz": round(self.idle[0] / self.idle[1] * wall_mhz, 1), "dependent_fma_per_us": round(self.idle[2] / self.idle[1] * wall_mhz, 1)}
+            out["fma_rate_vs_idle"] = round(out["dependent_fma_per_us"]["median"] / out["idle_gpu"]["dependent_fma_per_us"], 4)
+        return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,13 +385,26 @@ def main():
         selfcheck = D.gather_selfcheck(pred, gather.drain(), rank, world, elapsed_local=local_elapsed)
     sustained = None
     if world == 1 and args.sustained_steps > 0 and not args.no_graph:
-        with ClockSampler() as clk, torch.no_grad():
+        probe = None
+        try:
+            probe = ShaderClockProbe(dev)
+            probe.measure_idle()
+        except Exception as e:  # noqa: BLE001 - the probe is an extra; the leg is measured without it
+            log(f"shader clock probe unavailable: {e!r}")
+            probe = None
+        import contextlib
+        with ClockSampler() as clk, (probe or contextlib.nullcontext()), torch.no_grad():
             el_s = D.timed_steps(step_fn, args.sustained_steps, 2, sync=torch.cuda.synchronize)
         sustained = {"steps": args.sustained_steps, "seconds": round(el_s, 3), "value": round(args.batch * args.sustained_steps / el_s, 2),
                      "unit": "image-pairs/sec", "ms_per_step": round(el_s / args.sustained_steps * 1e3, 3),
                      # amdgpu sysfs pp_dpm_sclk level while the leg ran; only reported when it is a plausible shader clock (the file
                      # holds a power-state table on some driver versions)
-                     "sclk_sysfs_level_mhz": clk.mean_mhz if (clk.mean_mhz or 0) > 500 else None}
+                     "sclk_sysfs_level_mhz": clk.mean_mhz if (clk.mean_mhz or 0) > 500 else None,
+                     "shader_clock_under_load": probe.summary() if probe is not None else None}
+        sc = sustained["shader_clock_under_load"]
+        if sc and sc["s_memtime_mhz"]["median"] > 500 and dtype != torch.float32:
+            # the dense MFMA peak of MI355X_MICROARCH.md is quoted at the 2.4 GHz boost clock; this is the same machine at the clock it held
+            sc["bf16_mfma_peak_at_median_clock_tflops"] = round(PEAK_BF16_TFLOPS * sc["s_memtime_mhz"]["median"] / 2400.0, 1)
         log(f"sustained leg: {sustained}")
 
     if rank == 0:

@@ -39,6 +39,10 @@ enum {
 int cft_abi_version(void);
 int cft_device_check(void);               /* CFT_OK iff the current device is gfx950 */
 const char* cft_last_error(void);
+/* Measurement only (bench.py's sustained leg; no reference counterpart): a one-wave kernel that spins for spin_us microseconds of the
+ * constant-rate wall clock and writes out[0] = shader-clock ticks (s_memtime), out[1] = wall-clock ticks (s_memrealtime),
+ * out[2] = dependent v_fma_f32 executed meanwhile, out[3] = scratch; *wall_khz = rate of the wall clock.  out: 4 x uint64 in device memory. */
+int cft_clock_probe(void* out4_u64, int spin_us, int* wall_khz, void* stream);
 
 /*
  * Convolution as implicit GEMM with fused epilogue:

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ("runtime.hip", "conv_gemm.hip", "focus_conv.hip", "bottleneck.hip", "pointwise.hip", "attention.hip", "nms.hip", "train.hip")
 
 CFT_BF16, CFT_F32, CFT_F16 = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 
 _c = ctypes
@@ -28,6 +28,7 @@ _vp, _i, _l, _f = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float
 SIGNATURES = {
     "cft_abi_version": [],
     "cft_device_check": [],
+    "cft_clock_probe": [_vp, _i, _c.POINTER(_c.c_int), _vp],
     "cft_conv2d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_set_conv_variant": [_i],
     "cft_bottleneck": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

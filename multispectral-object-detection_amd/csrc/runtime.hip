@@ -20,7 +20,7 @@ int cft_check_launch(const char* what) {
   return CFT_OK;
 }
 
-extern "C" int cft_abi_version(void) { return 4; }   // 2: CFT_F16, dtype arguments of cft_bottleneck / cft_focus_conv, cft_to_nhwc; 3: w2_stages; 4: round 3 (probe exports removed, w2_stages required, permuted-row weights)
+extern "C" int cft_abi_version(void) { return 5; }   // 2: CFT_F16, dtype arguments of cft_bottleneck / cft_focus_conv, cft_to_nhwc; 3: w2_stages; 4: round 3 (probe exports removed, w2_stages required, permuted-row weights); 5: cft_clock_probe
 
 extern "C" const char* cft_last_error(void) { return g_err; }
 
@@ -36,4 +36,42 @@ extern "C" int cft_device_check(void) {
     return CFT_ENODEV;
   }
   return CFT_OK;
+}
+
+// Shader-clock probe (measurement only, bench.py's sustained leg): one wave runs a dependent chain of v_fma_f32 for `spin_us`
+// microseconds of the constant-rate wall clock (s_memrealtime) and reports the shader-clock ticks (s_memtime) and the FMAs it got
+// done meanwhile.  Launched on a side stream next to the forward, it reads the clock the SIMDs actually run at under that load:
+//   out[0] = shader-clock ticks, out[1] = wall-clock ticks, out[2] = dependent FMAs executed, out[3] = (keeps the chain live).
+__global__ void __launch_bounds__(64) clock_probe_kernel(unsigned long long* out, unsigned long long spin_ticks) {
+  const unsigned long long w0 = wall_clock64();
+  const unsigned long long c0 = clock64();
+  float a = 1.0f + threadIdx.x * 1e-7f;
+  const float b = 1.0000001f;
+  unsigned long long w1, n = 0;
+  do {
+#pragma unroll
+    for (int i = 0; i < 256; ++i) a = __builtin_fmaf(a, b, 1e-9f);
+    n += 256;
+    w1 = wall_clock64();
+  } while (w1 - w0 < spin_ticks);
+  const unsigned long long c1 = clock64();
+  if (threadIdx.x == 0) {
+    out[0] = c1 - c0;
+    out[1] = w1 - w0;
+    out[2] = n;
+    out[3] = (unsigned long long)__float_as_uint(a);
+  }
+}
+
+extern "C" int cft_clock_probe(void* out4_u64, int spin_us, int* wall_khz, void* stream) {
+  CFT_REQUIRE(out4_u64 != nullptr && wall_khz != nullptr && spin_us > 0 && spin_us <= 100000, "cft_clock_probe: bad argument");
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) {
+    cft_set_error("cft_clock_probe: wall clock rate not available");
+    return CFT_ENODEV;
+  }
+  *wall_khz = khz;
+  const unsigned long long ticks = (unsigned long long)spin_us * (unsigned long long)khz / 1000ull;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, as_stream(stream), (unsigned long long*)out4_u64, ticks);
+  return cft_check_launch("clock_probe_kernel");
 }

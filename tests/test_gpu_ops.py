@@ -543,3 +543,24 @@ def test_alternative_gemm_variants_are_bit_identical(dev, dtype, variant, case):
     got = to_cpu_f32(outs[variant])[:, :Cout]
     if not use_res:
         assert rel_err(got, ref) < tol(dtype)
+
+
+def test_clock_probe_reports_ticks_and_work(dev):
+    """cft_clock_probe (bench.py's shader-clock reading): spins for the requested wall-clock time and reports shader-clock
+    ticks, wall-clock ticks and the dependent FMAs executed; the shader clock it implies is a plausible GPU clock."""
+    import ctypes
+    from msod_amd import _lib
+    lib = _lib.load()
+    out = torch.zeros(4, dtype=torch.int64, device=dev)
+    khz = ctypes.c_int(0)
+    st = lib.cft_clock_probe(out.data_ptr(), 500, ctypes.byref(khz), torch.cuda.current_stream().cuda_stream)
+    assert st == 0, lib.cft_last_error()
+    torch.cuda.synchronize()
+    ticks, wall, fmas, _ = out.tolist()
+    assert khz.value > 0
+    us = wall / (khz.value / 1e3)
+    assert 500 <= us < 2000, us                      # at least the requested spin, not much more
+    assert fmas >= 256 and ticks > 0
+    mhz = ticks / us
+    assert 50 <= mhz <= 4000, mhz                    # s_memtime: the shader clock or a constant reference clock, never garbage
+    assert lib.cft_clock_probe(None, 500, ctypes.byref(khz), None) != 0 and b"cft_clock_probe" in lib.cft_last_error()
