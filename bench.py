@@ -183,48 +183,6 @@ def parity_at_bench_shape(dtype_name, got_raw, want_raw, ref16_raw=None, n_ref=0
     return out
 
 
-class ClockSampler:
-    """Shader clock during a sustained leg, from the amdgpu sysfs DPM table (the line marked '*' of pp_dpm_sclk), sampled
-    at 10 Hz by a thread; ``mean_mhz`` is None where the file is not readable.  Coarse: the table has few levels and the
-    driver reports the level, not the instantaneous clock - the sustained pairs/s next to the 20-step value is the evidence."""
-
-    def __init__(self):
-        import glob
-        import threading
-        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.samples, self.stop = [], threading.Event()
-        self.thread = threading.Thread(target=self._run, daemon=True)
-
-    def _read(self):
-        for p in self.paths:
-            try:
-                for ln in open(p).read().splitlines():
-                    if ln.rstrip().endswith("*"):
-                        return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
-            except (OSError, ValueError, IndexError):
-                continue
-        return None
-
-    def _run(self):
-        while not self.stop.is_set():
-            v = self._read()
-            if v is not None:
-                self.samples.append(v)
-            self.stop.wait(0.1)
-
-    def __enter__(self):
-        self.thread.start()
-        return self
-
-    def __exit__(self, *a):
-        self.stop.set()
-        self.thread.join(2)
-
-    @property
-    def mean_mhz(self):
-        return round(sum(self.samples) / len(self.samples), 1) if self.samples else None
-
-
 class ShaderClockProbe:
     """Shader clock the SIMDs run at while a leg is in flight, read from inside the GPU: every ``period`` seconds a thread
     launches ``cft_clock_probe`` (one wave, ``spin_us`` of the constant-rate wall clock) on its own stream next to the forward;
@@ -393,13 +351,10 @@ def main():
             log(f"shader clock probe unavailable: {e!r}")
             probe = None
         import contextlib
-        with ClockSampler() as clk, (probe or contextlib.nullcontext()), torch.no_grad():
+        with (probe or contextlib.nullcontext()), torch.no_grad():
             el_s = D.timed_steps(step_fn, args.sustained_steps, 2, sync=torch.cuda.synchronize)
         sustained = {"steps": args.sustained_steps, "seconds": round(el_s, 3), "value": round(args.batch * args.sustained_steps / el_s, 2),
                      "unit": "image-pairs/sec", "ms_per_step": round(el_s / args.sustained_steps * 1e3, 3),
-                     # amdgpu sysfs pp_dpm_sclk level while the leg ran; only reported when it is a plausible shader clock (the file
-                     # holds a power-state table on some driver versions)
-                     "sclk_sysfs_level_mhz": clk.mean_mhz if (clk.mean_mhz or 0) > 500 else None,
                      "shader_clock_under_load": probe.summary() if probe is not None else None}
         sc = sustained["shader_clock_under_load"]
         if sc and sc["s_memtime_mhz"]["median"] > 500 and dtype != torch.float32:
