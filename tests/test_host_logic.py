@@ -278,3 +278,28 @@ def test_bench_parity_check_flags_a_wrong_batch():
     assert not worse["ok"]
     assert bench.parity_at_bench_shape("f16", noise(0.002), want)["ok"] and not bench.parity_at_bench_shape("f16", noise(0.1), want)["ok"]
     assert bench.parity_at_bench_shape("f32", noise(1e-5), want)["ok"] and not bench.parity_at_bench_shape("f32", noise(0.01), want)["ok"]
+
+
+def test_shader_clock_summary_arithmetic():
+    """bench.py's reading of cft_clock_probe samples: MHz = shader ticks / wall ticks x wall-clock rate; the FMA rate against the idle probe."""
+    import ctypes
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pr = object.__new__(bench.ShaderClockProbe)          # no GPU: fill the fields the summary reads
+    pr.khz = ctypes.c_int(100000)                        # 100 MHz wall clock
+    pr.max = 4
+    pr.buf = torch.tensor([[420000, 20000, 80000, 0],    # 200 us at 2100 MHz, 400 FMA/us
+                           [400000, 20000, 76000, 0],    # 2000 MHz
+                           [440000, 20000, 84000, 0],    # 2200 MHz
+                           [0, 0, 0, 0],
+                           [480000, 20000, 90000, 0]], dtype=torch.int64)
+    pr.n = 4                                             # the fourth sample never ran (wall ticks 0): dropped
+    pr.idle = pr.buf[4].tolist()
+    s = pr.summary()
+    assert s["samples"] == 3 and s["s_memtime_mhz"] == {"median": 2100.0, "min": 2000.0, "max": 2200.0}
+    assert s["idle_gpu"]["s_memtime_mhz"] == 2400.0 and s["idle_gpu"]["dependent_fma_per_us"] == 450.0
+    assert abs(s["fma_rate_vs_idle"] - 400.0 / 450.0) < 1e-3
+    pr.n = 0
+    assert pr.summary() is None
