@@ -22,7 +22,13 @@ import statistics
 import sys
 import time
 
-import torch
+# HIP runtime knob, read when the runtime initialises (so: before torch is imported): kernel arguments are written straight into device
+# memory instead of being fetched from host memory at dispatch.  A forward is ~480 launches per HIP-graph replay, many of them 10-20 us
+# long: +1.7 % pairs/s with two forwards in flight, +1.9 % with one (profiles/r03_forwards_in_flight.txt).  A deployment sets the same
+# variable in its environment; an explicit setting of the caller wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -397,7 +403,7 @@ def main():
             "config": {"workload": f"{args.config} ({WORKLOADS.get(args.config, args.config)}) two-stream forward, "
                                    f"{args.size}x{args.size}, {args.batch} pairs/GPU, BN folded, pre-NMS detections",
                        "pairs_per_gpu": args.batch, "image_size": args.size, "parallelism": f"batch-shard x{world}",
-                       "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap, "forwards_in_flight": k_fly,
+                       "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap, "forwards_in_flight": k_fly, "env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
                        **({"stream_group_probe_ms_per_step": stream_probe_ms} if stream_probe_ms else {}),
                        **({"conv_variant": args.conv_variant} if args.conv_variant else {})},
             "sustained": sustained, "single_in_flight": single, "multi_gpu_selfcheck": selfcheck,
