@@ -269,11 +269,14 @@ def main():
     ap.add_argument("--sustained-steps", type=int, default=500, help="extra >= 10 s leg at N = 1 (0 = skip)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed configuration")
     ap.add_argument("--in-flight", type=int, default=2, help="forwards in flight (own graphs, buffers and streams each); 1 = one at a time")
+    ap.add_argument("--force-gather", action="store_true", help="N = 1: run the detection all-gather anyway (RCCL with world size 1, OverlappedGather "
+                    "inside the timed steps) and report multi_gpu_selfcheck - exercises the N > 1 step mode on the one GPU of a box")
     ap.add_argument("--conv-variant", type=int, default=0, help="A/B runs: cft_set_conv_variant() for the whole process (0 = automatic)")
     args = ap.parse_args()
 
     exit_code = 0
-    rank, world, local = D.init_from_env()
+    rank, world, local = D.init_from_env(force=args.force_gather)
+    gathering = world > 1 or args.force_gather
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", local if world > 1 else 0)
@@ -311,7 +314,7 @@ def main():
         pred, _ = step_seq()
         # N > 1: the all-gather of step i runs on RCCL's stream while the forward of step i+1 runs on the compute
         # stream (51.6 MB per rank per step would otherwise add ~10 % serial time); see distributed.OverlappedGather.
-        gather = D.OverlappedGather(pred, world) if world > 1 else None
+        gather = D.OverlappedGather(pred, world) if gathering else None
         # A step = one forward over one batch of `--batch` pairs.  With --in-flight K (default 2) step t replays graph t % K on HIP
         # stream t % K: consecutive steps are independent batches and overlap on the GPU (distributed.ForwardPipeline) - the
         # low-occupancy stretches of one forward (CFT blocks with M = 8192, the single-stream head) run under the other's
@@ -332,7 +335,7 @@ def main():
     assert all(torch.equal(c.pred, pred) for c in caps[1:]), "the graphs in flight disagree"
     log(f"timed region: {elapsed:.3f} s for {args.steps} steps ({k_fly} in flight)")
     local_elapsed = getattr(D.timed_steps, "last_local_elapsed", elapsed)
-    n_par = 0 if args.no_parity else min(args.batch, 8 if (world == 1 and not args.no_cpu_baseline) else 2)   # 8 pairs come free with the CPU leg (N = 1)
+    n_par = 0 if args.no_parity else min(args.batch, 8)     # the first 8 pairs of the timed batch, at every N (N > 1 lines checked 2)
     with torch.no_grad():
         raw_now = step_seq()[1]
         torch.cuda.synchronize()
@@ -345,8 +348,10 @@ def main():
                   "steps": args.steps, "note": "one forward in flight (each step starts when the previous one has finished)"}
         log(f"single in flight: {single}")
     selfcheck = None
-    if world > 1:       # evidence that every rank took part and that the gathered rows are the ranks' own rows
-        selfcheck = D.gather_selfcheck(pred, gather.drain(), rank, world, elapsed_local=local_elapsed)
+    if gathering:       # evidence that every rank took part and that the gathered rows are the ranks' own rows
+        selfcheck = D.gather_selfcheck(pred, gather.drain(), rank, world, elapsed_local=local_elapsed, force=args.force_gather)
+        if args.force_gather and world == 1:
+            selfcheck["note"] = "forced at N = 1: the collectives ran through RCCL with world size 1"
     sustained = None
     if world == 1 and args.sustained_steps > 0 and not args.no_graph:
         probe = None
@@ -479,7 +484,7 @@ def main():
         if not ok:
             log("PARITY FAILURE at the benchmarked shape - see parity_at_bench_shape in the line above")
             exit_code = 3
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     sys.exit(exit_code)

@@ -84,7 +84,8 @@ int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, int kpad1, 
 int cft_bottleneck_pack_w2(const void* w2, int kpad2, int c, void* w2_stages, int dtype, void* stream);
 
 /* Tuning knob: force one tile configuration of cft_conv2d (0 = automatic, the default; see
- * csrc/conv_gemm.hip for the table).  Returns the previous value.  Not needed for normal use. */
+ * csrc/conv_gemm.hip for the table).  The setting is PER HOST THREAD (thread_local): it reaches the launches the calling
+ * thread issues and no other's.  Returns the previous value.  Not needed for normal use. */
 int cft_set_conv_variant(int variant);
 
 /*

@@ -15,7 +15,9 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcft_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("runtime.hip", "conv_gemm.hip", "focus_conv.hip", "bottleneck.hip", "pointwise.hip", "attention.hip", "nms.hip", "train.hip")
+SOURCES = ("runtime.hip", "conv_gemm.hip", "conv_ring.hip", "focus_conv.hip", "bottleneck.hip", "pointwise.hip", "attention.hip", "nms.hip", "train.hip")
+
+HEADERS = ("cft_common.h", "conv_common.h")
 
 CFT_BF16, CFT_F32, CFT_F16 = 0, 1, 2
 ABI_VERSION = 5
@@ -58,12 +60,12 @@ _lib = None
 def build(verbose=False):
     """Compile every HIP source for gfx950 into ``libcft_hip.so`` next to this file."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    newest = max(os.path.getmtime(p) for p in srcs + [os.path.join(CSRC, "cft_common.h"),
-                                                       os.path.join(_HERE, "..", "include", "cft_hip.h")])
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(_HERE, "..", "include", "cft_hip.h")]
+    newest = max(os.path.getmtime(p) for p in srcs + hdrs)
     if os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
         return LIB_PATH
     # one object per source, compiled concurrently (only the stale ones), then one link
-    hdr_time = max(os.path.getmtime(os.path.join(CSRC, "cft_common.h")), os.path.getmtime(os.path.join(_HERE, "..", "include", "cft_hip.h")))
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
     obj_dir = os.path.join(_HERE, "build")
     os.makedirs(obj_dir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]

@@ -19,7 +19,7 @@
 #include <stdlib.h>
 
 #ifdef CFT_PROBES
-extern int g_conv_variant;   // conv_gemm.hip (cft_set_conv_variant)
+extern thread_local int g_conv_variant;   // conv_gemm.hip (cft_set_conv_variant)
 #endif
 
 __device__ __attribute__((aligned(16))) uint32_t cft_zero_page_b[4] = {0u, 0u, 0u, 0u};

@@ -28,7 +28,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
-// two floats -> packed half pair, round-to-nearest-even (v_cvt_f16_f32 x2 + v_pack_b32_f16)
+// two floats -> packed half pair, round-to-nearest-even: ONE v_cvt_pk_f16_f32 on gfx950 (checked in the ISA, profiles/r04_bf16_sites.md)
 __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));
 }

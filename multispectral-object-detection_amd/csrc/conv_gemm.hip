@@ -30,170 +30,7 @@
 //   -> rows re-read as 16-B vectors -> (+residual) -> one rounding -> coalesced 16-B stores.
 // Workgroup order is remapped so that consecutive logical tiles (which share A rows / neighbouring
 // image rows) run on the same XCD and hit the same 4 MiB L2.
-#include "cft_common.h"
-#include <stdlib.h>
-
-struct ConvParams {
-  const unsigned char* x;
-  const unsigned char* w;
-  const float* bias;
-  const unsigned char* res;
-  unsigned char* y;
-  int H, W, Cin, ldx, xoff;
-  int Ho, Wo, N, Kpad, K;
-  int ldy, yoff, ldr, roff;
-  int KS, stride, pad;
-  int act, out_f32, res_f32;
-  int M, tilesN;
-  uint32_t wo_mul, wo_sh, ho_mul, ho_sh;   // exact n / Wo and n / Ho for n < 2^31 as umulhi(n, mul) >> sh (mul == 0: divisor 1)
-};
-
-// floor(n / d) for 0 <= n < 2^31 with a host-computed (mul, sh): Granlund-Montgomery round-up method.
-__device__ __forceinline__ int fast_div(int n, uint32_t mul, uint32_t sh) {
-  return mul ? (int)(__umulhi((uint32_t)n, mul) >> sh) : n;
-}
-
-__device__ __attribute__((aligned(16))) uint32_t cft_zero_page[4] = {0u, 0u, 0u, 0u};
-// UNIK path: weight rows beyond N point at this zero REGION and still advance along K (no per-step select): 64 KiB >= 2 * Kpad + 128
-constexpr int CFT_ZERO_REGION_BYTES = 65536;
-__device__ __attribute__((aligned(128))) uint32_t cft_zero_region[CFT_ZERO_REGION_BYTES / 4];   // zero-initialised
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void gbl_void_t;
-
-// Epilogue (wave-private, no workgroup barriers - the LDS operations of one wave are ordered):
-// acc (+bias, activation) -> 16-row fp32 LDS strip -> rows re-read as 16-B vectors -> (+residual)
-// -> one rounding -> coalesced 16-B stores.  The caller guarantees (barrier) that no wave still
-// reads the staging buffers that the strips alias.
-template <typename TH, int WM, int WN, int ACT, bool OUT_F32>   // TH: the 16-bit storage type (bf16 bits or half)
-__device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4_t (&acc)[WM / 16][WN / 16], unsigned char* smem,
-                                                   int m0, int n0, int wm, int wn, int wave, int lane, const float (&bias_v)[WN / 16]) {
-  constexpr int MT = WM / 16, NT = WN / 16;
-  const int lrow = lane & 15, lgrp = lane >> 4;
-  constexpr int SLD = WN + 4;  // fp32 strip leading dimension (+4: the four 4-row lane groups hit different banks)
-  float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SLD);
-  // bf16 residual (Bottleneck shortcut): every strip's residual vectors are requested up front, so their HBM
-  // latency runs under the activation / LDS work instead of once per strip.  (The lane that reads an element is
-  // the lane that later stores it, so an in-place residual stays correct.)
-  constexpr int VPRB = WN / 8;                       // 16-B bf16 vectors per strip row
-  constexpr int VPL = (16 * VPRB + 63) / 64;         // vectors per lane per strip
-  constexpr int RDEPTH = (MT * VPL <= 6) ? MT : 2;   // strips of residual in flight (register budget: 16-wave tiles keep 2)
-  gran_t rpre[OUT_F32 ? 1 : RDEPTH][OUT_F32 ? 1 : VPL];
-  const bool res_pre = !OUT_F32 && p.res != nullptr && !p.res_f32;   // uniform
-#define CFT_RES_FETCH(strip_)                                                                          \
-  _Pragma("unroll") for (int v_ = 0; v_ < VPL; ++v_) {                                                 \
-    const int it_ = lane + v_ * 64;                                                                    \
-    const int row_ = it_ / VPRB, col_ = (it_ - row_ * VPRB) * 8;                                       \
-    const int m_ = m0 + wm * WM + (strip_) * 16 + row_, n_ = n0 + wn * WN + col_;                      \
-    gran_t t_ = {0u, 0u, 0u, 0u};                                                                      \
-    if (it_ < 16 * VPRB && m_ < p.M && n_ < p.N)                                                       \
-      t_ = *reinterpret_cast<const gran_t*>(p.res + ((long)m_ * p.ldr + p.roff + n_) * 2);             \
-    rpre[(strip_) % RDEPTH][v_] = t_;                                                                  \
-  }
-  if constexpr (!OUT_F32) {
-    if (res_pre) {
-#pragma unroll
-      for (int i = 0; i < RDEPTH; ++i) CFT_RES_FETCH(i)
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        stage[(lgrp * 4 + e) * SLD + j * 16 + lrow] = apply_act<ACT>(acc[i][j][e] + bias_v[j]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int mbase = m0 + wm * WM + i * 16;
-    const int nbase = n0 + wn * WN;
-    if constexpr (OUT_F32) {
-      constexpr int VPR = WN / 4;  // 16-B vectors per strip row
-      for (int it = lane; it < 16 * VPR; it += 64) {
-        const int row = it / VPR, col = (it - row * VPR) * 4;
-        const int m = mbase + row, n = nbase + col;
-        if (m < p.M && n < p.N) {
-          const f32x4_t sv = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col);
-          float v[4] = {sv[0], sv[1], sv[2], sv[3]};
-          if (p.res != nullptr) {
-            const long ro = (long)m * p.ldr + p.roff + n;
-            if (p.res_f32) {
-              const float4 rr = *reinterpret_cast<const float4*>(p.res + ro * 4);
-              v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-            } else {
-              const uint2 rr = *reinterpret_cast<const uint2*>(p.res + ro * 2);
-              float r0, r1, r2, r3;
-              Elem<TH>::unpack2(rr.x, r0, r1);
-              Elem<TH>::unpack2(rr.y, r2, r3);
-              v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
-            }
-          }
-          *reinterpret_cast<f32x4_t*>(p.y + ((long)m * p.ldy + p.yoff + n) * 4) = f32x4_t{v[0], v[1], v[2], v[3]};
-        }
-      }
-    } else {
-      constexpr int VPR = WN / 8;
-#pragma unroll
-      for (int vi = 0; vi < VPL; ++vi) {
-        const int it = lane + vi * 64;
-        const int row = it / VPR, col = (it - row * VPR) * 8;
-        const int m = mbase + row, n = nbase + col;
-        if (it < 16 * VPR && m < p.M && n < p.N) {
-          const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col);
-          const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col + 4);
-          float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-          if (res_pre) {
-            float rf[8];
-            Elem<TH>::unpack(rpre[i % RDEPTH][vi], rf);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rf[e];
-          } else if (p.res != nullptr) {   // fp32 residual stream of the CFT block
-            const long ro = (long)m * p.ldr + p.roff + n;
-            const float4 r0v = *reinterpret_cast<const float4*>(p.res + ro * 4);
-            const float4 r1v = *reinterpret_cast<const float4*>(p.res + ro * 4 + 16);
-            v[0] += r0v.x; v[1] += r0v.y; v[2] += r0v.z; v[3] += r0v.w;
-            v[4] += r1v.x; v[5] += r1v.y; v[6] += r1v.z; v[7] += r1v.w;
-          }
-          *reinterpret_cast<gran_t*>(p.y + ((long)m * p.ldy + p.yoff + n) * 2) = Elem<TH>::pack(v);
-        }
-      }
-      if (res_pre && i + RDEPTH < MT) CFT_RES_FETCH(i + RDEPTH)
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-}
-
-#undef CFT_RES_FETCH
-
-// This lane's bias values (output column j*16 + lrow of the wave tile).  Loaded BEFORE the K loop: at the epilogue the value
-// is a register, not an exposed L2 round trip per workgroup (and an ordinary load result consumed next to LDS-DMA traffic
-// makes hipcc drain vmcnt to 0 at that point).
-template <int WN>
-__device__ __forceinline__ void conv_load_bias(const ConvParams& p, int n0, int wn, int lane, float (&bias_v)[WN / 16]) {
-#pragma unroll
-  for (int j = 0; j < WN / 16; ++j) {
-    const int n = n0 + wn * WN + j * 16 + (lane & 15);
-    bias_v[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.0f;
-  }
-}
-
-// Uniform dispatch to the specialised epilogues (one activation / output type per launch).
-template <typename TH, int WM, int WN>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc)[WM / 16][WN / 16], unsigned char* smem,
-                                              int m0, int n0, int wm, int wn, int wave, int lane, const float (&bias_v)[WN / 16]) {
-  if (p.out_f32) {
-    if (p.act == CFT_ACT_SILU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_SILU, true>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
-    else if (p.act == CFT_ACT_GELU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_GELU, true>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
-    else conv_epilogue_impl<TH, WM, WN, CFT_ACT_NONE, true>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
-  } else {
-    if (p.act == CFT_ACT_SILU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_SILU, false>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
-    else if (p.act == CFT_ACT_GELU) conv_epilogue_impl<TH, WM, WN, CFT_ACT_GELU, false>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
-    else conv_epilogue_impl<TH, WM, WN, CFT_ACT_NONE, false>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
-  }
-}
+#include "conv_common.h"
 
 // ABLATE (tuning only, bit mask): 1 = no global loads after the first tile (compute-only bound); 2 = no MFMA
 // (staging-only bound); 16 = no epilogue (no bias/activation/residual/stores).
@@ -454,7 +291,8 @@ static void set_magic(int d, uint32_t& mul, uint32_t& sh) {
 
 
 // Tile variants.  0 = automatic choice; the others force one configuration (tuning / A-B tests).
-int g_conv_variant = 0;   // also read by bottleneck.hip in probe builds (-DCFT_PROBES)
+// Per host thread (two forwards may be issued from two threads; a test's cft_set_conv_variant must not reach the other's launches).
+thread_local int g_conv_variant = 0;   // also read by bottleneck.hip in probe builds (-DCFT_PROBES)
 extern "C" int cft_set_conv_variant(int v) {
   const int old = g_conv_variant;
   g_conv_variant = v;
@@ -482,9 +320,23 @@ static int launch_auto(const ConvParams& p, hipStream_t stream) {
   return launch_conv<T, BM, BN, WGM, WGN, true>(p, stream);
 }
 
+// Eligibility of the ring kernel: 16-bit operands, Cin a multiple of the 64-wide K step (uniform walk), no K padding.
+template <typename T>
+static bool ring_ok(const ConvParams& p) {
+  // (the last clause: masked granules are fetched at the out-of-range buffer offset 2^31, so both buffers must end below it)
+  return sizeof(T) == 2 && p.Cin % 64 == 0 && p.Kpad == p.K && p.KS <= 3 &&
+         p.x_bytes + 2L * ((long)p.W + 1) * p.ldx < (1L << 31) && p.w_bytes < (1L << 31);
+}
+
+template <typename T, int ABLATE = 0>
+static int launch_ring(const ConvParams& p, hipStream_t stream) {
+  return conv_ring_launch(p, sizeof(T) != 2 ? CFT_F32 : (__is_same(T, f16_t) ? CFT_F16 : CFT_BF16), ABLATE, stream);   // conv_ring.hip
+}
+
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   switch (g_conv_variant) {
+    case 91: if (ring_ok<T>(p)) return launch_ring<T>(p, stream); return launch_auto<T, 256, 256, 4, 4>(p, stream);   // ring kernel wherever eligible (tests)
     case 1: return launch_conv<T, 128, 128, 2, 2, false>(p, stream);   // register-staged baseline
     case 2: return launch_auto<T, 128, 128, 2, 2>(p, stream);
     case 4: return launch_auto<T, 128, 64, 2, 2>(p, stream);
@@ -514,6 +366,9 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
     case 127: return launch_conv<T, 256, 256, 4, 4, true, 1>(p, stream);
     case 227: return launch_conv<T, 256, 256, 4, 4, true, 2>(p, stream);
     case 327: return launch_conv<T, 256, 256, 4, 4, true, 3>(p, stream);
+    case 190: if (ring_ok<T>(p)) return launch_ring<T, 1>(p, stream); break;    // ring kernel: no global loads after the prologue's
+    case 290: if (ring_ok<T>(p)) return launch_ring<T, 2>(p, stream); break;    // no MFMAs
+    case 1690: if (ring_ok<T>(p)) return launch_ring<T, 16>(p, stream); break;  // no epilogue
 #endif
     default: break;
   }
@@ -549,7 +404,10 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   // wide layers: prefer 256-wide tiles unless the N tail would waste much more than 128-wide tiles do
   const long pad256 = (long)((p.N + 255) / 256) * 256, pad128 = (long)((p.N + 127) / 128) * 128;
   const bool wide_ok = pad256 * 100 <= pad128 * 115;
-  if (wide_ok && p.Kpad >= 256 && tiles(256, 256) >= kCUs) return launch_auto<T, 256, 256, 4, 4>(p, stream);
+  if (wide_ok && p.Kpad >= 256 && tiles(256, 256) >= kCUs) {
+    if (g_conv_variant == 90 && ring_ok<T>(p)) return launch_ring<T>(p, stream);    // A/B: the ring kernel in place of the 16-wave 256x256 tile
+    return launch_auto<T, 256, 256, 4, 4>(p, stream);
+  }
   if (wide_ok && tiles(128, 256) >= kCUs) return launch_auto<T, 128, 256, 4, 4>(p, stream);   // e.g. CFT fc2 at M = 8192
   if (tiles(192, 128) >= 2 * kCUs) return launch_auto<T, 192, 128, 2, 4>(p, stream);
   if (tiles(128, 128) >= 2 * kCUs) return launch_auto<T, 128, 128, 2, 4>(p, stream);
@@ -586,6 +444,8 @@ extern "C" int cft_conv2d(const void* x, const void* w, const float* bias, const
   p.KS = ksize; p.stride = stride; p.pad = pad;
   p.act = act; p.out_f32 = out_dtype == CFT_F32; p.res_f32 = res_dtype == CFT_F32;
   p.M = (int)M; p.tilesN = 0;
+  p.x_bytes = (long)B * H * W * ldx * cft_elem_size(dtype);
+  p.w_bytes = (long)n * kpad * cft_elem_size(dtype);
   set_magic(Wo, p.wo_mul, p.wo_sh);
   set_magic(Ho, p.ho_mul, p.ho_sh);
   CFT_DISPATCH_DTYPE(dtype, T, return dispatch_conv<T>(p, as_stream(stream)));

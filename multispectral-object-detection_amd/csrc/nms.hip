@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(1024) nms_kernel(const float* __restrict__ pre
     }
     const bool in_lds = m <= NMS_CHUNK && kept_in_lds;    // uniform
     if (in_lds) {
-      // gather the chunk into LDS (order irrelevant: the arg-max breaks ties by key)
+      // gather the chunk into LDS (in any order: it is sorted by (score, key) below)
       __syncthreads();
       if (tid == 0) s_m = 0;
       __syncthreads();
@@ -220,16 +220,16 @@ __global__ void __launch_bounds__(1024) nms_kernel(const float* __restrict__ pre
       //      resolves the block sequentially in registers (next live candidate is kept, the candidates it suppresses
       //      are cleared), then all threads clear the LATER candidates that the block's new detections suppress.
       // Every IoU test is the same call as before (later candidate against the kept box); exact.
-      int P = 64;
-      while (P < m) P <<= 1;                                     // bitonic size
-      for (int j = tid; j < P; j += 1024) {
+      int npow2 = 64;
+      while (npow2 < m) npow2 <<= 1;                                     // bitonic size
+      for (int j = tid; j < npow2; j += 1024) {
         c_org[j] = j;
         if (j >= m) { c_sc[j] = -1.f; c_key[j] = 0x7fffffff; }
       }
       __syncthreads();
-      for (int k = 2; k <= P; k <<= 1) {
+      for (int k = 2; k <= npow2; k <<= 1) {
         for (int jj = k >> 1; jj > 0; jj >>= 1) {
-          for (int i = tid; i < P; i += 1024) {
+          for (int i = tid; i < npow2; i += 1024) {
             const int l = i ^ jj;
             if (l > i) {
               const bool first_half = (i & k) == 0;             // "better first" in the first half of each 2k run, reversed in the second

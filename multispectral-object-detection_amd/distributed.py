@@ -13,13 +13,22 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun convention, same env
-    contract as reference train.py:960-961,989-995).  Returns (rank, world_size, local_rank)."""
+    contract as reference train.py:960-961,989-995).  Returns (rank, world_size, local_rank).
+    ``force``: also build a process group when WORLD_SIZE is 1 (rendezvous on 127.0.0.1), so that the collective path
+    - RCCL communicator, its stream, ``OverlappedGather`` - can be exercised on the one GPU a box has."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if force and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -187,15 +196,16 @@ class OverlappedGather:
         return self.out[(self.tick - 1) & 1] if self.tick else None
 
 
-def gather_selfcheck(local, gathered, rank, world, elapsed_local=None, group=None, gather_probe_steps=3):
+def gather_selfcheck(local, gathered, rank, world, elapsed_local=None, group=None, gather_probe_steps=3, force=False):
     """Evidence for an N > 1 bench line, computed from collectives so that a stub or a silently
     single-rank run cannot produce it: ``n_ranks_seen`` = ranks that contributed to an all-gather of their rank ids;
     ``rows_ok`` = rank 0's gathered rows [B r, B (r+1)) equal rank r's local tensor (compared through a float64
     sum, a float64 sum of squares and 16 strided samples that every rank all-gathers); ``per_rank_elapsed_s`` = every
     rank's own timed-region seconds; ``gather_ms`` = median wall time of ``gather_probe_steps`` synchronous gathers.
-    Returns a dict on every rank (identical content)."""
+    Returns a dict on every rank (identical content).  ``force``: run the collectives with a one-rank group too
+    (``init_from_env(force=True)``: they then go through RCCL with world size 1 instead of being skipped)."""
     import statistics
-    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
     if not multi:
         return {"n_ranks_seen": 1, "rows_ok": True, "per_rank_elapsed_s": [elapsed_local], "gather_ms": 0.0}
     dev = local.device
@@ -236,7 +246,9 @@ class ForwardPipeline:
     so consecutive steps overlap on the GPU while the steps of one runner stay ordered on its stream.  Consecutive
     inference steps are independent (different batches in deployment), which is what makes this legal; it is the compute
     counterpart of ``OverlappedGather`` (step t's collective under step t + 1's forward).  ``gather`` (optional): every
-    step's output is submitted to it on the step's stream."""
+    step's output is submitted to it on the step's stream.
+    Ordering contract: ``step()`` does NOT order its stream after the caller's current stream - whoever writes a runner's
+    input buffers must make those writes complete (or make ``streams[i]`` wait for them) before the step that reads them."""
 
     def __init__(self, runners, streams=None, gather=None):
         self.runners, self.streams, self.gather, self.tick = list(runners), streams, gather, 0
@@ -250,6 +262,7 @@ class ForwardPipeline:
         profiles/r03_forwards_in_flight.txt).  This draws ``groups`` candidate groups of K streams, times ``probe_steps`` steps per
         forward on each and returns the fastest group (plus the measured table)."""
         k = len(runners)
+        torch.cuda.synchronize(device)      # the runners' inputs (written on the caller's stream) are complete before any probe replays them
         cands = [[torch.cuda.Stream(device=device) for _ in range(k)] for _ in range(groups)]
         table = []
         for streams in cands:

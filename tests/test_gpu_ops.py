@@ -317,7 +317,7 @@ def test_conv3x3_wide_layers_at_the_benchmarked_row_count(dev, dtype, shape):
     lib = _lib.load()
     outs = {}
     try:
-        for variant in (0, 27, 60, 51):
+        for variant in (0, 27, 60, 51, 90, 91):
             lib.cft_set_conv_variant(variant)
             y = ops.conv2d(xd, pk, 1, residual=rd)
             torch.cuda.synchronize()
@@ -497,7 +497,8 @@ def test_plain_nchw_tensor_into_a_module(dev, dtype):
     assert torch.equal(z[:, :12].float().cpu(), _q(_rnd(2, 12, 5, 7, seed=82), dtype)) and z[:, 12:].abs().max() == 0
 
 
-ALT_VARIANTS = [0, 27, 51]   # automatic choice / forced big tiles with the uniform-K-walk address path (UNIK) where the layer allows it,
+ALT_VARIANTS = [0, 27, 51, 91]   # (91 = the ring-staged 8-wave 256x256 kernel wherever the layer is eligible)
+# automatic choice / forced big tiles with the uniform-K-walk address path (UNIK) where the layer allows it,
 # against variant 900 = the generic per-thread address path
 STAGGERED_CASES = [
     # B, H, W, Cin, Cout, k, s, residual

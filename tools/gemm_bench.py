@@ -69,9 +69,12 @@ def main():
     ap.add_argument("--used", action="store_true", help="only the shapes that occur in the cfg3 forward (count > 0)")
     ap.add_argument("--out", default="gemm_bench.json")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--lib", default="", help="load this library instead of the product one (tools/build_probes.sh: libcft_hip_probes.so with the timing probes)")
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
     dev = torch.device("cuda:0")
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     lib = _lib.load()
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
     results = []

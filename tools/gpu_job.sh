@@ -71,6 +71,38 @@ PY
   tiles)       # tile choice re-check with the interleaved, warmed per-shape timing: automatic choice against the forced tile variants
     timeout 1200 python tools/gemm_bench.py --used --variants ${1:-0,27,60,51,23,33,30,6,63,2} --rounds 3 --out $JOB/gemm.json > $O/gemm.log 2>&1; echo "gemm rc=$?" | tee $O/summary.txt
     grep -E "^variant|^best" $O/gemm.log ;;
+  r4a)         # round 4, first call: L2->LDS stream microbenchmark, ring GEMM kernel (variant 90) bit-identity + per-shape A/B + probes, runtime knobs
+    timeout 120 tools/micro/dma_ring > $O/dma_ring.txt 2>&1; echo "dma rc=$?" | tee $O/summary.txt; tail -64 $O/dma_ring.txt
+    timeout 900 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "alternative_gemm or wide_layers" > $O/tests.log 2>&1; echo "tests rc=$?" | tee -a $O/summary.txt; tail -4 $O/tests.log
+    WIDE="3x3s2 128->256|C3 1x1 256->256|3x3s2 256->512|C3 1x1 512->512|bneck 1x1 256->256|bneck 3x3 256->256|3x3s2 512->1024|bneck 3x3 512->512|1x1 1024->1024|SPP cv2|GPT|quant"
+    timeout 600 python tools/gemm_bench.py --variants 0,91 --only "$WIDE" --rounds 3 --out $JOB/gemm_ring_ab.json > $O/gemm.log 2>&1; echo "gemm rc=$?" | tee -a $O/summary.txt
+    python - <<PY
+import json
+for r in json.load(open("gpurun_out/$JOB/gemm_ring_ab.json")):
+    v = r["variants"]
+    print(f'{r["shape"]:42s} auto {v["0"]["us"]:7.1f} us {v["0"]["tflops"]:7.1f} TF | ring {v["91"]["us"]:7.1f} us {v["91"]["tflops"]:7.1f} TF  diff {v["91"]["maxdiff_vs_first"]}')
+PY
+    grep -E "^variant|^best" $O/gemm.log
+    if [ -f multispectral-object-detection_amd/libcft_hip_probes.so ]; then
+      timeout 600 python tools/gemm_bench.py --lib multispectral-object-detection_amd/libcft_hip_probes.so --variants 27,127,227,1627,91,190,290,1690 --only "bneck 3x3 256->256|GPT fc1 1024|C3 1x1 512->512|quant 3x3" --rounds 3 --out $JOB/gemm_ring_probes.json > $O/probes.log 2>&1; echo "probes rc=$?" | tee -a $O/summary.txt
+      python - <<PY
+import json
+for r in json.load(open("gpurun_out/$JOB/gemm_ring_probes.json")):
+    print(r["shape"], {k: v.get("us") for k, v in r["variants"].items()})
+PY
+    fi
+    X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
+    run() { tag=$1; shift; timeout 300 env "$@" python bench.py $X $ARGS > $O/b.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/b.json'));print('$tag', d['value'], d['ms_per_step'], (d.get('single_in_flight') or {}).get('value'), d['config'].get('stream_group_probe_ms_per_step'))" | tee -a $O/summary.txt; }
+    ARGS="--in-flight 2"; run "default q, 2 in flight" A=1
+    ARGS="--in-flight 2"; run "GPU_MAX_HW_QUEUES=8, 2 in flight" GPU_MAX_HW_QUEUES=8
+    ARGS="--in-flight 3"; run "GPU_MAX_HW_QUEUES=8, 3 in flight" GPU_MAX_HW_QUEUES=8
+    ARGS="--in-flight 3"; run "default q, 3 in flight" A=1
+    ARGS="--in-flight 2 --steps 200"; run "kernarg=0" HIP_FORCE_DEV_KERNARG=0
+    ARGS="--in-flight 2 --steps 200"; run "kernarg=1" HIP_FORCE_DEV_KERNARG=1
+    ARGS="--in-flight 2 --steps 200"; run "kernarg=0" HIP_FORCE_DEV_KERNARG=0
+    ARGS="--in-flight 2 --steps 200"; run "kernarg=1" HIP_FORCE_DEV_KERNARG=1
+    ARGS="--in-flight 2 --conv-variant 90"; run "ring kernel (variant 90) on the wide layers, 2 in flight" A=1
+    ARGS="--in-flight 2"; run "default again" A=1 ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
