@@ -100,13 +100,14 @@ def traffic_from_profile(args, n_launch, abytes):
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh ->
     profiles/*_traffic.json: FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, summed
     over the conv_gemm family of one forward).  Only reported for the configuration it was collected on."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (3, 2, 1)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (4, 3, 2, 1)) if os.path.exists(q)), None)
     if path is None:
         return None
     t = json.load(open(path))
     if (t.get("config"), t.get("batch"), t.get("size"), t.get("dtype")) != (args.config, args.batch, args.size, args.dtype):
         return None
     return {"bytes_per_launch": t["gemm_bytes_per_forward"] / n_launch, "algorithmic_bytes_per_launch": abytes / n_launch,
+            "all_kernels_bytes_per_forward": t.get("all_kernels_bytes_per_forward"),
             "source": f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
 
 
@@ -159,6 +160,14 @@ def cpu_baseline(cfg, sd, rgb, ir, budget_s=30.0):
 
 
 BOUNDS = {"f32": ("raw logits max-abs", 1e-3), "f16": ("sigmoid-space max-abs", 1e-2), "bf16": ("sigmoid-space max-abs", 2.5e-2)}
+# What a 16-bit leg is gated on, in words: fp16 meets north_star's literal 1e-2 and is the declared parity-green 16-bit mode;
+# bf16 cannot on these weights (two thirds of its error is the single rounding of the WEIGHTS, profiles/r04_bf16_sites.md: the reference's own
+# bf16-autocast forward is at the same 1.4e-2) and is gated on that reference level instead.
+GATES = {"f32": "north_star 1e-3 on raw logits vs the fp32 oracle",
+         "f16": "north_star 1e-2 (sigmoid space) vs the fp32 oracle - the parity-green 16-bit mode, the reference's own GPU precision (test.py:66-68)",
+         "bf16": "NOT the literal 1e-2: <= 2.5e-2 AND at least as close to fp32 as the reference's own bf16-autocast forward on the same weights "
+                 "and inputs (max <= 1.30x + 1e-3, rms <= 1.10x); see parity_green_dtype for the 16-bit mode that meets 1e-2"}
+HBM_ACHIEVABLE_TBPS, HBM_SPEC_TBPS = 6.29, 8.0      # MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured (float4 copy)
 REF_BF16_MAX_RATIO, REF_BF16_RMS_RATIO = 1.30, 1.10     # as tests/test_gpu_model.py: HIP bf16 error level vs the reference-style bf16 forward
 
 
@@ -174,7 +183,8 @@ def parity_at_bench_shape(dtype_name, got_raw, want_raw, ref16_raw=None, n_ref=0
     what, bound = BOUNDS[dtype_name]
     g, w = _flat(got_raw), _flat(want_raw)
     err = (g - w).abs().max().item() if dtype_name == "f32" else (g.sigmoid() - w.sigmoid()).abs().max().item()
-    out = {"pairs": int(got_raw[0].shape[0]), "check": what, "max_err": round(err, 6), "bound": bound,
+    out = {"pairs": int(got_raw[0].shape[0]), "check": what, "gate": GATES[dtype_name], "max_err": round(err, 6), "bound": bound,
+           "meets_north_star_bound": bool(err <= (1e-3 if dtype_name == "f32" else 1e-2)),
            "rms_logit_err_over_std": round(((g - w).pow(2).mean().sqrt() / w.std()).item(), 6), "ok": bool(err <= bound)}
     if ref16_raw is not None and n_ref:
         g2, w2, r2 = _flat([r[:n_ref] for r in got_raw]), _flat([r[:n_ref] for r in want_raw]), _flat(ref16_raw)
@@ -261,6 +271,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--no-concat-plan", action="store_true", help="A/B: let Concat copy all its sources")
+    ap.add_argument("--no-cft-fusion", action="store_true", help="A/B: de-tokenise + Add2 per stream and Add as three launches (round 3) instead of one")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-f16-leg", action="store_true", help="skip the extra fp16 measurement (N = 1, 16-bit runs only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -294,6 +305,7 @@ def main():
     model = model.to(dev).fuse().set_compute_dtype(dtype)   # deployed form: BN folded (attempt_load does .fuse())
     model.overlap_streams = not args.no_overlap
     model.plan_concats = not args.no_concat_plan
+    model.fuse_cft_outputs = not args.no_cft_fusion
     rgb, ir = seeded_inputs(args.batch, args.size, args.size, seed=rank)
     rgb, ir = rgb.to(dev), ir.to(dev)
 
@@ -426,6 +438,24 @@ def main():
                          "top_shapes": [{"shape": k, "launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
                                          "ms": round(v[2] * 1e3, 3)} for k, v in top]},
         }
+        # Both floors of the whole step: the matrix floor at the dense peak and the HBM floor on the step's own bytes
+        # (algorithmic = every logged kernel's inputs once + outputs once; counters = the PMC profile of the same configuration).  The
+        # larger one binds: for cfg3 at 64 pairs that is HBM, although 99.6 % of the FLOPs are MFMA work.
+        rl = line["roofline"]
+        alg_bytes = abytes + sum(v[3] for v in aux.values())
+        tr = rl["traffic"] or {}
+        floors = {"mfma_ms": round((flops + sum(v[1] for v in aux.values())) / (peak * 1e12) * 1e3, 3),
+                  "hbm_ms_algorithmic": round(alg_bytes / (HBM_ACHIEVABLE_TBPS * 1e12) * 1e3, 3),
+                  "hbm_ms_counters": round(tr["all_kernels_bytes_per_forward"] / (HBM_ACHIEVABLE_TBPS * 1e12) * 1e3, 3) if tr.get("all_kernels_bytes_per_forward") else None,
+                  "algorithmic_gbytes_per_step": round(alg_bytes / 1e9, 2),
+                  "hbm_rate": f"{HBM_ACHIEVABLE_TBPS} TB/s achievable (spec {HBM_SPEC_TBPS}); algorithmic bytes cover the GEMM family and the CFT pointwise kernels "
+                              "(SPP / concat copies / Add / Detect decode are not logged: < 2 % of the bytes)"}
+        binding = max(v for v in (floors["mfma_ms"], floors["hbm_ms_algorithmic"], floors["hbm_ms_counters"]) if v is not None)
+        rl["floors"] = floors
+        rl["frac_of_binding_floor"] = round(binding / ms, 4)
+        rl["whole_step_bound"] = "hbm" if binding > floors["mfma_ms"] else "mfma"
+        rl["bound_note"] = ("'bound' names what bounds the dominant KERNEL FAMILY the achieved / peak pair is about (MFMA: 99.6 % of the FLOPs); the whole "
+                            "step is bound by 'whole_step_bound' - see 'floors'")
         if args.dtype == "bf16" and world == 1 and not args.no_f16_leg and not args.no_graph:
             # the same step in fp16 - the 16-bit type that meets the 1e-2 parity bound: same MFMA
             # rate and bytes as bf16, measured with the same loop
@@ -480,6 +510,14 @@ def main():
             if "f16" in line and got_raw16 is not None:
                 line["f16"]["parity_at_bench_shape"] = parity_at_bench_shape("f16", got_raw16, want_raw)
                 ok = ok and line["f16"]["parity_at_bench_shape"]["ok"]
+            # the 16-bit mode of THIS line that meets north_star's literal bound at the benchmarked shape (fp32 runs: the run itself)
+            legs = {args.dtype: line["parity_at_bench_shape"]}
+            if "f16" in line and "parity_at_bench_shape" in line["f16"]:
+                legs["f16"] = line["f16"]["parity_at_bench_shape"]
+            green = [d for d in ("f16", "bf16", "f32") if d in legs and legs[d]["ok"] and legs[d]["meets_north_star_bound"]]
+            line["parity_green_dtype"] = green[0] if green else None
+            if line["parity_green_dtype"] == "f16" and "f16" in line:
+                line["parity_green_value"] = line["f16"]["value"]
         print(json.dumps(line), flush=True)
         if not ok:
             log("PARITY FAILURE at the benchmarked shape - see parity_at_bench_shape in the line above")

@@ -194,6 +194,15 @@ int cft_gpt_upsample_add(const float* tokens, int s, const void* base, int ldb, 
                          int dtype, void* stream);
 
 /*
+ * The same for BOTH streams of a CFT block in one launch, plus the Add that consumes the two results (models/common.py:626-637 twice,
+ * Add2 :238-243 twice, Add :228-229):  out0 = base0 + up(tokens[:, :64]), out1 = base1 + up(tokens[:, 64:]),
+ * sum (may be NULL) = out0 + out1 formed in fp32 before the one rounding.  out0 / out1 are bit-identical to two cft_gpt_upsample_add calls.
+ */
+int cft_gpt_upsample_add2(const float* tokens, const void* base0, int ldb0, int boff0, const void* base1, int ldb1, int boff1,
+                          void* out0, int ldo0, int ooff0, void* out1, int ldo1, int ooff1, void* sum, int lds, int soff,
+                          int B, int H, int W, int C, int dtype, void* stream);
+
+/*
  * Detect decode (models/yolo_test.py:47-57).  logits: float [B,ny,nx,ldl] holding na*no valid
  * channels (channel = a*no + o), the output of the 1x1 conv.  Writes
  *   raw [B,na,ny,nx,no]            = logits permuted (the reference's x[i])

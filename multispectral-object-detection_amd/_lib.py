@@ -20,7 +20,7 @@ SOURCES = ("runtime.hip", "conv_gemm.hip", "conv_ring.hip", "focus_conv.hip", "b
 HEADERS = ("cft_common.h", "conv_common.h")
 
 CFT_BF16, CFT_F32, CFT_F16 = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 
 _c = ctypes
@@ -50,6 +50,7 @@ SIGNATURES = {
     "cft_dropout": [_vp, _l, _f, _c.c_ulonglong, _i, _vp],
     "cft_batchnorm_train_workspace": [_l, _i],      # returns long (bytes)
     "cft_gpt_upsample_add": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_gpt_upsample_add2": [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_nms": [_vp, _i, _i, _i, _f, _f, _i, _i, _vp, _i, _i, _vp, _l, _vp, _vp, _vp],
     "cft_detect_decode": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _l, _vp],
 }

@@ -320,6 +320,7 @@ static int launch_auto(const ConvParams& p, hipStream_t stream) {
   return launch_conv<T, BM, BN, WGM, WGN, true>(p, stream);
 }
 
+#ifdef CFT_PROBES
 // Eligibility of the ring kernel: 16-bit operands, Cin a multiple of the 64-wide K step (uniform walk), no K padding.
 template <typename T>
 static bool ring_ok(const ConvParams& p) {
@@ -332,11 +333,11 @@ template <typename T, int ABLATE = 0>
 static int launch_ring(const ConvParams& p, hipStream_t stream) {
   return conv_ring_launch(p, sizeof(T) != 2 ? CFT_F32 : (__is_same(T, f16_t) ? CFT_F16 : CFT_BF16), ABLATE, stream);   // conv_ring.hip
 }
+#endif
 
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   switch (g_conv_variant) {
-    case 91: if (ring_ok<T>(p)) return launch_ring<T>(p, stream); return launch_auto<T, 256, 256, 4, 4>(p, stream);   // ring kernel wherever eligible (tests)
     case 1: return launch_conv<T, 128, 128, 2, 2, false>(p, stream);   // register-staged baseline
     case 2: return launch_auto<T, 128, 128, 2, 2>(p, stream);
     case 4: return launch_auto<T, 128, 64, 2, 2>(p, stream);
@@ -366,6 +367,7 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
     case 127: return launch_conv<T, 256, 256, 4, 4, true, 1>(p, stream);
     case 227: return launch_conv<T, 256, 256, 4, 4, true, 2>(p, stream);
     case 327: return launch_conv<T, 256, 256, 4, 4, true, 3>(p, stream);
+    case 91: if (ring_ok<T>(p)) return launch_ring<T>(p, stream); return launch_auto<T, 256, 256, 4, 4>(p, stream);   // the 8-wave kernel wherever eligible
     case 190: if (ring_ok<T>(p)) return launch_ring<T, 1>(p, stream); break;    // ring kernel: no global loads after the prologue's
     case 290: if (ring_ok<T>(p)) return launch_ring<T, 2>(p, stream); break;    // no MFMAs
     case 1690: if (ring_ok<T>(p)) return launch_ring<T, 16>(p, stream); break;  // no epilogue
@@ -405,7 +407,9 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   const long pad256 = (long)((p.N + 255) / 256) * 256, pad128 = (long)((p.N + 127) / 128) * 128;
   const bool wide_ok = pad256 * 100 <= pad128 * 115;
   if (wide_ok && p.Kpad >= 256 && tiles(256, 256) >= kCUs) {
-    if (g_conv_variant == 90 && ring_ok<T>(p)) return launch_ring<T>(p, stream);    // A/B: the ring kernel in place of the 16-wave 256x256 tile
+#ifdef CFT_PROBES
+    if (g_conv_variant == 90 && ring_ok<T>(p)) return launch_ring<T>(p, stream);    // A/B: the 8-wave kernel in place of the 16-wave 256x256 tile
+#endif
     return launch_auto<T, 256, 256, 4, 4>(p, stream);
   }
   if (wide_ok && tiles(128, 256) >= kCUs) return launch_auto<T, 128, 256, 4, 4>(p, stream);   // e.g. CFT fc2 at M = 8192

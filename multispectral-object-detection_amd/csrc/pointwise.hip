@@ -541,6 +541,86 @@ extern "C" int cft_gpt_upsample_add(const float* tokens, int s, const void* base
   return cft_check_launch("gpt_upsample_add_kernel");
 }
 
+// Both streams of a CFT block in ONE launch, with the Add that follows them in the graph (yaml rows 11-12 + 29 of the x3 configs):
+//   out0 = base0 + up(tokens[:, :64]),  out1 = base1 + up(tokens[:, 64:]),  sum = out0 + out1 (optional)
+// (models/common.py:626-637 twice + Add2 :238-243 twice + Add :228-229).  One launch instead of three, the two base maps are read once
+// instead of once + once more by Add, and the sum is formed from the UNROUNDED fp32 sums: one rounding per output tensor (the
+// reference adds in fp32 throughout; profiles/r04_bf16_sites.md lists Add / Add2 among the activation-side rounding sites).
+template <typename T>
+__global__ void __launch_bounds__(256) gpt_upsample_add2_kernel(const float* __restrict__ tokens,
+                                                                const unsigned char* base0, long ldb0_b, long boff0_b,
+                                                                const unsigned char* base1, long ldb1_b, long boff1_b,
+                                                                unsigned char* out0, long ldo0_b, long ooff0_b,
+                                                                unsigned char* out1, long ldo1_b, long ooff1_b,
+                                                                unsigned char* sum, long lds_b, long soff_b,
+                                                                int B, int H, int W, int C) {
+  constexpr int GE = Elem<T>::GE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* R = reinterpret_cast<float*>(smem);          // [2][8][C]: the row's vertical interpolation of both streams' tokens
+  const int b = blockIdx.x / H, y = blockIdx.x - b * H;
+  float fy = ((float)y + 0.5f) * (8.0f / (float)H) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+  const int y0 = (int)fy, y1 = y0 + (y0 < 7 ? 1 : 0);
+  const float ly = fy - (float)y0, hy = 1.f - ly;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float* t0 = tokens + ((long)b * 128 + s * 64 + y0 * 8) * C;
+    const float* t1 = tokens + ((long)b * 128 + s * 64 + y1 * 8) * C;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+      const float4 a = reinterpret_cast<const float4*>(t0)[i], c = reinterpret_cast<const float4*>(t1)[i];
+      reinterpret_cast<float4*>(R + s * 8 * C)[i] = make_float4(hy * a.x + ly * c.x, hy * a.y + ly * c.y, hy * a.z + ly * c.z, hy * a.w + ly * c.w);
+    }
+  }
+  __syncthreads();
+  const int gpp = C / GE;
+  const float sx = 8.0f / (float)W;
+  const long rowpix = ((long)b * H + y) * W;
+  for (int idx = threadIdx.x; idx < W * gpp; idx += blockDim.x) {
+    const int x = idx / gpp, cg = idx - x * gpp;
+    float fx = ((float)x + 0.5f) * sx - 0.5f; fx = fx < 0.f ? 0.f : fx;
+    const int x0 = (int)fx, x1 = x0 + (x0 < 7 ? 1 : 0);
+    const float lx = fx - (float)x0, hx = 1.f - lx;
+    const long pix = rowpix + x;
+    float v0[GE], v1[GE];
+    Elem<T>::unpack(*reinterpret_cast<const gran_t*>(base0 + pix * ldb0_b + boff0_b + cg * 16L), v0);
+    Elem<T>::unpack(*reinterpret_cast<const gran_t*>(base1 + pix * ldb1_b + boff1_b + cg * 16L), v1);
+    const float* r0 = R + x0 * C + cg * GE;
+    const float* r1 = R + x1 * C + cg * GE;
+#pragma unroll
+    for (int e = 0; e < GE; ++e) {            // the same expression as gpt_upsample_add_kernel: out0 / out1 are bit-identical to it
+      v0[e] += hx * r0[e] + lx * r1[e];
+      v1[e] += hx * r0[8 * C + e] + lx * r1[8 * C + e];
+    }
+    *reinterpret_cast<gran_t*>(out0 + pix * ldo0_b + ooff0_b + cg * 16L) = Elem<T>::pack(v0);
+    *reinterpret_cast<gran_t*>(out1 + pix * ldo1_b + ooff1_b + cg * 16L) = Elem<T>::pack(v1);
+    if (sum != nullptr) {
+#pragma unroll
+      for (int e = 0; e < GE; ++e) v0[e] += v1[e];
+      *reinterpret_cast<gran_t*>(sum + pix * lds_b + soff_b + cg * 16L) = Elem<T>::pack(v0);
+    }
+  }
+}
+
+extern "C" int cft_gpt_upsample_add2(const float* tokens, const void* base0, int ldb0, int boff0, const void* base1, int ldb1, int boff1,
+                                     void* out0, int ldo0, int ooff0, void* out1, int ldo1, int ooff1, void* sum, int lds, int soff,
+                                     int B, int H, int W, int C, int dtype, void* stream) {
+  CFT_REQUIRE(tokens && base0 && base1 && out0 && out1, "cft_gpt_upsample_add2: null pointer");
+  CFT_REQUIRE(cft_is_dtype(dtype), "cft_gpt_upsample_add2: bad dtype");
+  const int ge = cft_granule(dtype), es = cft_elem_size(dtype);
+  CFT_REQUIRE(C % ge == 0 && ldb0 % ge == 0 && boff0 % ge == 0 && ldb1 % ge == 0 && boff1 % ge == 0 && ldo0 % ge == 0 && ooff0 % ge == 0 &&
+              ldo1 % ge == 0 && ooff1 % ge == 0 && (sum == nullptr || (lds % ge == 0 && soff % ge == 0)), "cft_gpt_upsample_add2: not granule aligned");
+  CFT_REQUIRE(C % 4 == 0 && (long)B * H < (1L << 31), "cft_gpt_upsample_add2: C must be a multiple of 4");
+  const int smem = 2 * 8 * C * (int)sizeof(float);
+  CFT_REQUIRE(smem <= 128 * 1024, "cft_gpt_upsample_add2: C too large for the LDS rows (C <= 2048)");
+  CFT_DISPATCH_DTYPE(dtype, T, {
+    cft_allow_lds<&gpt_upsample_add2_kernel<T>>(128 * 1024);
+    hipLaunchKernelGGL(gpt_upsample_add2_kernel<T>, dim3(B * H), dim3(256), smem, as_stream(stream), tokens,
+                       (const unsigned char*)base0, (long)ldb0 * es, (long)boff0 * es, (const unsigned char*)base1, (long)ldb1 * es, (long)boff1 * es,
+                       (unsigned char*)out0, (long)ldo0 * es, (long)ooff0 * es, (unsigned char*)out1, (long)ldo1 * es, (long)ooff1 * es,
+                       (unsigned char*)sum, (long)lds * es, (long)soff * es, B, H, W, C);
+  });
+  return cft_check_launch("gpt_upsample_add2_kernel");
+}
+
 // ------------------------------------------------------------------------------- Detect decode
 __global__ void __launch_bounds__(256) detect_decode_kernel(const float* __restrict__ logits, int ldl, float* __restrict__ raw,
                                                             float* __restrict__ pred, const float* __restrict__ anchors,

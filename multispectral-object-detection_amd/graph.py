@@ -21,12 +21,12 @@ class CapturedForward:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(warmup):                  # first launches set kernel attributes, pack weights
-                model.forward_once(self.rgb, self.ir)
+                model.forward_once(self.rgb, self.ir, until_detect=True)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.pred, self.raw = model.forward_once(self.rgb, self.ir)
+            self.pred, self.raw = model.forward_once(self.rgb, self.ir, until_detect=True)
         self.weights_key = model.weights_key()     # Model.forward drops the graph when the weights change
 
     def replay(self, rgb, ir):

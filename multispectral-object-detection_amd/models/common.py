@@ -541,6 +541,92 @@ BottleneckCSP = _outside("BottleneckCSP", "models/common.py:112-128")
 C3TR = _outside("C3TR", "models/common.py:146-151")
 Contract = _outside("Contract", "models/common.py:183-194")
 Expand = _outside("Expand", "models/common.py:197-208")
-NMS = _outside("NMS", "models/common.py:247-257")
-autoShape = _outside("autoShape", "models/common.py:260-327")
+
+
+class NMS(nn.Module):
+    """Non-maximum-suppression module (reference models/common.py:247-257): what ``Model.nms()`` appends behind ``Detect``.
+    ``forward(x)`` takes Detect's ``(pred, raw)`` and returns the per-image detection list of ``non_max_suppression`` -
+    here ONE batched HIP kernel (``cft_nms``) instead of a Python loop around ``torchvision.ops.nms``."""
+    conf = 0.25      # confidence threshold
+    iou = 0.45       # IoU threshold
+    classes = None   # (optional list) filter by class
+
+    def forward(self, x):
+        from ..utils.general import non_max_suppression
+        return non_max_suppression(x[0], conf_thres=self.conf, iou_thres=self.iou, classes=self.classes)
+
+
+class autoShape(nn.Module):
+    """Input-robust wrapper (reference models/common.py:260-327) in the TWO-STREAM form the reference never finished: its
+    ``autoShape.forward`` hands ONE image batch to a ``Model`` whose ``forward(x, x2)`` needs two (the call raises for every
+    fusion yaml).  Here ``forward(rgb, ir, size=640)`` takes, per stream, one image or a list of images - HWC uint8 numpy arrays or
+    tensors in RGB order (``cv2.imread(...)[:, :, ::-1]``, ``np.asarray(PIL.Image)``), or CHW - or two ready BCHW float tensors
+    (passed straight to the model like the reference does, :283-285).  Pre-processing follows :288-309 (common inference
+    shape = the largest scaled image rounded up to the stride, ``letterbox(auto=False)``, BHWC -> BCHW, / 255) with the letterbox on
+    the device (``cft_letterbox_u8``) and the / 255 fused into Focus; post-processing :317-320 (``non_max_suppression`` =
+    ``cft_nms``, ``scale_coords`` back to every original image).  Returns the list of per-image ``[n, 6]`` (xyxy, conf, cls)
+    tensors in ORIGINAL-image pixels (the reference wraps the same list in its plotting class ``Detections``, out of scope)."""
+    conf = 0.25
+    iou = 0.45
+    classes = None
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = model.eval()
+        for k in ("yaml", "nc", "hyp", "names", "stride"):          # copy_attr(m, self, include=(...)) of reference :312-313
+            if hasattr(model, k):
+                setattr(self, k, getattr(model, k))
+
+    def autoshape(self):
+        return self      # already wrapped (reference :271-273)
+
+    @staticmethod
+    def _hwc_u8(im, device):
+        import numpy as np
+        if isinstance(im, torch.Tensor):
+            t = im
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(im)))
+        if t.dim() == 2:
+            t = t[:, :, None].expand(-1, -1, 3)
+        if t.shape[0] < 5:                                          # CHW -> HWC (reference :298-299)
+            t = t.permute(1, 2, 0)
+        t = t[:, :, :3]
+        if t.dtype != torch.uint8:
+            raise TypeError("autoShape: images must be uint8 (or pass two BCHW float tensors)")
+        return t.contiguous().to(device)
+
+    @torch.no_grad()
+    def forward(self, rgb, ir, size=640, augment=False, profile=False):
+        from ..models.yolo_test import make_divisible
+        from ..utils.datasets import letterbox
+        from ..utils.general import non_max_suppression, scale_coords
+        p = next(self.model.parameters())
+        if isinstance(rgb, torch.Tensor) and rgb.dim() == 4:        # ready batches: straight to the model
+            return self.model(rgb.to(p.device), ir.to(p.device), augment, profile)
+        rgbs = list(rgb) if isinstance(rgb, (list, tuple)) else [rgb]
+        irs = list(ir) if isinstance(ir, (list, tuple)) else [ir]
+        if len(rgbs) != len(irs):
+            raise ValueError("autoShape: the two streams must hold the same number of images")
+        rgbs = [self._hwc_u8(im, p.device) for im in rgbs]
+        irs = [self._hwc_u8(im, p.device) for im in irs]
+        shape0 = [tuple(int(v) for v in im.shape[:2]) for im in rgbs]
+        if any(tuple(b.shape[:2]) != s for b, s in zip(irs, shape0)):
+            raise ValueError("autoShape: an RGB / IR pair must have the same height and width (aligned pairs)")
+        smax = int(self.stride.max()) if hasattr(self, "stride") else 32
+        shape1 = [max(s[d] * (size / max(s)) for s in shape0) for d in (0, 1)]
+        shape1 = [make_divisible(v, smax) for v in shape1]          # one inference shape for the batch (:304)
+        n = len(rgbs)
+        batch = torch.empty((n, 6, shape1[0], shape1[1]), dtype=torch.uint8, device=p.device)
+        for i in range(n):                                          # BGR->RGB flip is not wanted here (inputs are RGB): HWC out, then permute
+            a, _, _ = letterbox(rgbs[i], new_shape=shape1, auto=False)
+            b, _, _ = letterbox(irs[i], new_shape=shape1, auto=False)
+            batch[i, :3] = a.permute(2, 0, 1)
+            batch[i, 3:] = b.permute(2, 0, 1)
+        y = self.model(batch[:, :3], batch[:, 3:])[0]               # uint8 views: Focus normalises (/255) while it reads
+        y = non_max_suppression(y, conf_thres=self.conf, iou_thres=self.iou, classes=self.classes)
+        for i in range(n):
+            scale_coords(shape1, y[i][:, :4], shape0[i])
+        return y
+
 Classify = _outside("Classify", "models/common.py:417-427")

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .common import (GPT, SPP, Add, Add2, Bottleneck, C3, Concat, Conv, Focus, Upsample, _Packed, resolve,
+from .common import (GPT, NMS, SPP, Add, Add2, Bottleneck, C3, Concat, Conv, Focus, PendingBilinear, Upsample, _Packed, autoShape, resolve,
                      ACT_NONE, invalidate_packed)
 
 logger = logging.getLogger(__name__)
@@ -243,7 +243,8 @@ class Model(nn.Module):
         g = None if (self.training or profile) else self._graphs.get(key)     # profile: per-layer events need eager launches
         if g is not None:
             if g.weights_key == self.weights_key():
-                return g.replay(x, x2)
+                out = g.replay(x, x2)
+                return self.model[-1](out) if type(self.model[-1]) is NMS else out      # the graph ends at Detect (NMS syncs with the host)
             self._graphs.clear()            # weights changed since capture: the graph would replay the old ones
         return self.forward_once(x, x2, profile)
 
@@ -331,6 +332,70 @@ class Model(nn.Module):
         self.__dict__["_concat_plan"] = plan
         return plan
 
+    # ---- CFT output fusion: both Add2 layers behind a GPT block and the Add that sums them run as ONE kernel ----------------
+    def cft_fusion_plan(self):
+        """{index of the first Add2 behind a GPT block: (GPT index, index of the second Add2, index of the Add that consumes both
+        or None)} - yaml rows 10-12 + 29 (17-19 + 30, 26-28 + 31) of the x3 configs.  The pattern is matched structurally; a config
+        without it (add-fusion, 4-GPT variants with other wiring) simply has no entries."""
+        plan = self.__dict__.get("_cft_plan")
+        if plan is not None:
+            return plan
+        layers = list(self.model)
+        src = lambda i, j: i + j if j < 0 else j      # noqa: E731
+        plan = {}
+        for i, m in enumerate(layers):
+            if not isinstance(m, GPT) or not isinstance(m.f, (list, tuple)) or len(m.f) != 2:
+                continue
+            adds = [j for j, a in enumerate(layers) if isinstance(a, Add2) and isinstance(a.f, (list, tuple)) and len(a.f) == 2
+                    and src(j, a.f[1]) == i]
+            if len(adds) != 2 or {layers[adds[0]].index, layers[adds[1]].index} != {0, 1}:
+                continue
+            j1, j2 = adds
+            gin = [src(i, f) for f in m.f]
+            if src(j1, layers[j1].f[0]) != gin[layers[j1].index] or src(j2, layers[j2].f[0]) != gin[layers[j2].index]:
+                continue                               # an Add2 whose base is not the GPT's own input of that stream
+            k = next((kk for kk, a in enumerate(layers) if type(a) is Add and isinstance(a.f, (list, tuple))
+                      and sorted(src(kk, f) for f in a.f) == [j1, j2]), None)
+            plan[j1] = (i, j2, k)
+        self.__dict__["_cft_plan"] = plan
+        return plan
+
+    def _fused_cft_outputs(self, m, x, y, cbufs):
+        """Layer ``m`` is the first Add2 of a planned group and its GPT input is still deferred: run the dual de-tokeniser
+        (``cft_gpt_upsample_add2``) and return {layer index: output} for the group, else None."""
+        ent = self.cft_fusion_plan().get(m.i)
+        if ent is None or not isinstance(x, (list, tuple)) or not isinstance(x[1], (list, tuple)):
+            return None
+        i, j2, k = ent
+        p0, p1 = x[1][0], x[1][1]
+        if not (isinstance(p0, PendingBilinear) and isinstance(p1, PendingBilinear) and p0.tokens is p1.tokens):
+            return None
+        layers = self.model
+        src = lambda a, j: a + j if j < 0 else j      # noqa: E731
+        base_m = resolve(x[0])
+        base_o = y[src(j2, layers[j2].f[0])]
+        if base_o is None or not base_m.is_cuda:
+            return None
+        base_o = resolve(base_o)
+        bases = [None, None]
+        bases[m.index], bases[layers[j2].index] = base_m, base_o
+        sum_out = None
+        if k is not None and cbufs is not None:       # the Add's planned concat slice (what _run_layer would hand to Add.forward)
+            tgt = self.concat_plan().get(k)
+            if tgt is not None:
+                cidx, off, c, total = tgt
+                B, _, H, W = base_m.shape
+                buf = cbufs.get(cidx)
+                if buf is None:
+                    buf = cbufs[cidx] = ops.new_nhwc(B, H, W, total, base_m.dtype, base_m.device)
+                if tuple(buf.shape) == (B, total, H, W):
+                    sum_out = buf[:, off:off + c]
+        o0, o1, osum = ops.gpt_upsample_add_dual(p0.tokens, bases[0], bases[1], p0.H, p0.W, p0.dtype, sum_out=sum_out, want_sum=k is not None)
+        outs = {m.i: (o0, o1)[m.index], j2: (o0, o1)[layers[j2].index]}
+        if k is not None:
+            outs[k] = osum
+        return outs
+
     def _run_layer(self, m, x, x2, cbufs):
         if m.f == -4:
             return m(x2)
@@ -352,16 +417,22 @@ class Model(nn.Module):
             return m(x, out=cbufs[m.i])
         return m(x)
 
-    def forward_once(self, x, x2, profile=False):
+    def forward_once(self, x, x2, profile=False, until_detect=False):
         """Graph walk of reference models/yolo_test.py:235-272: ``f == -1`` previous output, int /
         list = saved outputs, ``f == -4`` = this layer consumes the IR image ``x2``.
+        ``until_detect``: stop in front of a trailing ``NMS`` module (HIP-graph capture: NMS reads its counts on the host).
 
         The two backbones are independent between fusion points, so with ``overlap_streams`` they are
         enqueued on two HIP streams (fork/join by stream waits; inside a HIP-graph capture this becomes
         two parallel branches of the graph).  Every tensor that crosses lanes is a saved layer output
         and stays referenced in ``y`` until the walk ends, so the caching allocator cannot recycle it
         under a kernel of the other stream."""
+        layers = list(self.model)
+        if until_detect and layers and type(layers[-1]) is NMS:
+            layers = layers[:-1]
         lanes = self.stream_lanes() if (self.overlap_streams and x.is_cuda and not profile) else None
+        fused = {}                                                    # outputs of a CFT output group still to be handed to their layers
+        fuse_cft = x.is_cuda and self.__dict__.get("fuse_cft_outputs", True)
         cbufs = {} if (x.is_cuda and self.__dict__.get("plan_concats", True)) else None   # planned concat buffers of this walk
         if lanes is None or 1 not in lanes:
             y, marks = [], []
@@ -369,13 +440,21 @@ class Model(nn.Module):
                 flog, prev_log = [], ops._launch_log         # every layer, GFLOPS from the algorithmic FLOPs of its GEMM launches
                 ops.set_launch_log(flog)
             try:
-                for m in self.model:
+                for m in layers:
                     if m.f != -1 and m.f != -4:
                         x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
                     if profile:
                         e0, e1, n0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), len(flog)
                         e0.record()
-                    x = self._run_layer(m, x, x2, cbufs)
+                    if m.i in fused:
+                        x = fused.pop(m.i)
+                    else:
+                        grp = self._fused_cft_outputs(m, x, y, cbufs) if fuse_cft else None
+                        if grp is not None:
+                            x = grp.pop(m.i)
+                            fused.update(grp)
+                        else:
+                            x = self._run_layer(m, x, x2, cbufs)
                     if profile:
                         e1.record()
                         marks.append((m, e0, e1, sum(rec[1] for rec in flog[n0:])))
@@ -398,7 +477,7 @@ class Model(nn.Module):
         streams = (main, side)
         side.wait_stream(main)                       # fork: the side lane starts after everything queued so far
         y, keep = [], []
-        for i, m in enumerate(self.model):
+        for i, m in enumerate(layers):
             lane = lanes[i]
             f = m.f
             srcs = [] if (f == -4 or i == 0) else ([i - 1] if f == -1 else ([f % i] if isinstance(f, int) else [(i - 1 if j == -1 else j % i) for j in f]))
@@ -407,7 +486,15 @@ class Model(nn.Module):
             if f != -1 and f != -4:
                 x = y[f] if isinstance(f, int) else [x if j == -1 else y[j] for j in f]
             with torch.cuda.stream(streams[lane]):
-                x = self._run_layer(m, x, x2, cbufs)
+                if m.i in fused:
+                    x = fused.pop(m.i)       # produced by the group's kernel on the other lane: the cross-lane wait above orders it
+                else:
+                    grp = self._fused_cft_outputs(m, x, y, cbufs) if fuse_cft else None
+                    if grp is not None:
+                        x = grp.pop(m.i)
+                        fused.update(grp)
+                    else:
+                        x = self._run_layer(m, x, x2, cbufs)
             keep.append(x)                           # keep every output alive until both lanes have joined
             y.append(x if m.i in self.save else None)
         main.wait_stream(side)                       # join
@@ -420,6 +507,37 @@ class Model(nn.Module):
             b.data[:, 4] += math.log(8 / (640 / s) ** 2)
             b.data[:, 5:] += math.log(0.6 / (m.nc - 0.99)) if cf is None else torch.log(cf / cf.sum())
             mi.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
+
+    def _print_biases(self):  # reference :284-289
+        m = self.model[-1] if isinstance(self.model[-1], Detect) else self.model[-2]
+        for mi in m.m:
+            b = mi.bias.detach().view(m.na, -1).T
+            logger.info(("%6g Conv2d.bias:" + "%10.3g" * 6) % (mi.weight.shape[1], *b[:5].mean(1).tolist(), b[5:].mean()))
+
+    def nms(self, mode=True):
+        """Add or remove the NMS module behind ``Detect`` (reference :306-318): with it ``model(x, x2)`` returns the per-image
+        detection lists.  The module runs ``cft_nms``; a captured HIP graph covers the layers in front of it."""
+        present = type(self.model[-1]) is NMS
+        if mode and not present:
+            logger.info("Adding NMS... ")
+            m = NMS()
+            m.f = -1
+            m.i = self.model[-1].i + 1
+            m.type, m.np = "models.common.NMS", 0
+            self.model.add_module(name="%s" % m.i, module=m)
+            self.eval()
+        elif not mode and present:
+            logger.info("Removing NMS... ")
+            self.model = self.model[:-1]
+        self.__dict__.pop("_concat_plan", None)
+        self.__dict__.pop("_cft_plan", None)
+        self._graphs.clear()
+        return self
+
+    def autoshape(self):
+        """Wrap the model for raw image input (reference :320-324); see ``models.common.autoShape`` (two-stream form)."""
+        logger.info("Adding autoShape... ")
+        return autoShape(self)
 
     def fuse(self):
         """Fold every BatchNorm into its conv (reference :296-304, utils/torch_utils.py:181-201).

@@ -455,6 +455,37 @@ def gpt_upsample_add(tokens, s, base, H, W, dtype):
     return out
 
 
+def gpt_upsample_add_dual(tokens, base0, base1, H, W, dtype, sum_out=None, want_sum=True):
+    """Both streams of a CFT block and the Add behind them in one kernel (cft_gpt_upsample_add2):
+    returns (base0 + up(tokens[:, :64]), base1 + up(tokens[:, 64:]), their sum or None); ``sum_out``: write the sum there
+    (e.g. a channel slice of a planned concat buffer)."""
+    _require_cuda(tokens, "gpt_upsample_add_dual")
+    B, T, C = tokens.shape
+    base0, ldb0 = as_nhwc(base0)
+    base1, ldb1 = as_nhwc(base1)
+    for bse in (base0, base1):
+        if tuple(bse.shape) != (B, C, H, W) or bse.dtype != dtype:
+            raise ValueError("gpt_upsample_add_dual: base shape/dtype mismatch")
+    out0 = new_nhwc(B, H, W, C, dtype, tokens.device)
+    out1 = new_nhwc(B, H, W, C, dtype, tokens.device)
+    sp, lds = None, 0
+    if want_sum:
+        if sum_out is None:
+            sum_out = new_nhwc(B, H, W, C, dtype, tokens.device)
+        if tuple(sum_out.shape) != (B, C, H, W) or sum_out.dtype != dtype:
+            raise ValueError("gpt_upsample_add_dual: sum_out shape/dtype mismatch")
+        lds = _view_ld(sum_out, "gpt_upsample_add_dual sum")
+        sp = sum_out.data_ptr()
+    else:
+        sum_out = None
+    lib = _lib.load()
+    st = _timed("cft_upsample_add", 0.0, (5.0 if want_sum else 4.0) * B * H * W * C * out0.element_size(),
+                lambda: lib.cft_gpt_upsample_add2(tokens.data_ptr(), base0.data_ptr(), ldb0, 0, base1.data_ptr(), ldb1, 0,
+                                                  out0.data_ptr(), C, 0, out1.data_ptr(), C, 0, sp, lds, 0, B, H, W, C, _dt(dtype), _stream()))
+    _lib.check(st, "cft_gpt_upsample_add2")
+    return out0, out1, sum_out
+
+
 def detect_decode(logits, raw, pred, anchors_px, na, no, stride, row0):
     """logits [B, ldl, ny, nx] NHWC float32; raw [B,na,ny,nx,no]; pred [B,rows,no] (filled at row0)."""
     B, ldl, ny, nx = logits.shape

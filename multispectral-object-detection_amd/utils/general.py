@@ -23,10 +23,12 @@ def _class_table(classes, nc, device):
 
 
 def batched_nms(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300,
-                max_nms=MAX_NMS):
+                max_nms=MAX_NMS, class_table=None):
     """prediction [B, rows, nc+5] (fp32, on the GPU) -> (dets [B, max_det, 6] = (x1,y1,x2,y2,conf,cls),
-    counts [B] int32).  No host synchronisation (unless ``classes`` is given as a Python list: one small H2D copy):
-    fit for HIP-graph capture and for all-gathering the <= max_det survivors instead of all rows."""
+    counts [B] int32).  ``classes`` is ALWAYS a collection of class ids, as in the reference (:505-506; a list or a tensor
+    on any device: one small H2D copy); ``class_table`` instead hands over a ready-made uint8 [nc] allow-table on the
+    prediction's device (1 = keep the class) - no host work at all: fit for HIP-graph capture and for all-gathering the
+    <= max_det survivors instead of all rows."""
     _require_cuda(prediction, "batched_nms")
     if prediction.dtype != torch.float32 or not prediction.is_contiguous():
         prediction = prediction.float().contiguous()
@@ -37,10 +39,14 @@ def batched_nms(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnos
     scratch = torch.empty((B * ((cap + 3) // 4 * 4) * 32,), dtype=torch.uint8, device=prediction.device)
     dets = torch.empty((B, max_det, 6), dtype=torch.float32, device=prediction.device)     # cft_nms zeroes the unused rows itself
     counts = torch.empty((B,), dtype=torch.int32, device=prediction.device)                 # and always writes every count
-    if isinstance(classes, torch.Tensor) and classes.dtype == torch.uint8 and classes.numel() == nc and classes.is_cuda \
-            and classes.device == prediction.device and classes.is_contiguous():
-        allow = classes                       # a ready-made [nc] allow-table on the device (the kernel indexes it by class id)
-    else:                                     # anything else is a collection of class ids (reference :505-506)
+    if class_table is not None:
+        if classes is not None:
+            raise ValueError("batched_nms: give either classes (ids) or class_table (allow-table), not both")
+        if not (isinstance(class_table, torch.Tensor) and class_table.dtype == torch.uint8 and class_table.numel() == nc
+                and class_table.device == prediction.device and class_table.is_contiguous()):
+            raise ValueError(f"batched_nms: class_table must be a contiguous uint8 [{nc}] tensor on {prediction.device}")
+        allow = class_table                   # the kernel indexes it by class id
+    else:
         allow = _class_table(classes.tolist() if isinstance(classes, torch.Tensor) else classes, nc, prediction.device)
     st = _lib.load().cft_nms(prediction.data_ptr(), B, rows, no, float(conf_thres), float(iou_thres), int(bool(agnostic)),
                              int(multi_label), allow.data_ptr() if allow is not None else None, int(max_det), int(max_nms),
@@ -79,3 +85,26 @@ def xywh2xyxy(x):
     y[..., 2] = x[..., 0] + x[..., 2] / 2
     y[..., 3] = x[..., 1] + x[..., 3] / 2
     return y
+
+
+def clip_coords(boxes, img_shape):
+    """Clip xyxy boxes to the image (height, width), in place (reference utils/general.py:369-374)."""
+    boxes[:, 0].clamp_(0, img_shape[1])
+    boxes[:, 1].clamp_(0, img_shape[0])
+    boxes[:, 2].clamp_(0, img_shape[1])
+    boxes[:, 3].clamp_(0, img_shape[0])
+
+
+def scale_coords(img1_shape, coords, img0_shape, ratio_pad=None):
+    """Map xyxy boxes from the letterboxed shape back to the original image, in place (reference utils/general.py:353-366)."""
+    if ratio_pad is None:
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    else:
+        gain = ratio_pad[0][0]
+        pad = ratio_pad[1]
+    coords[:, [0, 2]] -= pad[0]
+    coords[:, [1, 3]] -= pad[1]
+    coords[:, :4] /= gain
+    clip_coords(coords, img0_shape)
+    return coords

@@ -390,6 +390,35 @@ def test_two_forwards_in_flight_do_not_interfere(dev):
         assert torch.equal(c.pred, w)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_cft_output_fusion_matches_the_three_launch_path(dev, dtype):
+    """Model.cft_fusion_plan: the two Add2 layers behind every GPT block and the Add that sums them run as one kernel
+    (cft_gpt_upsample_add2).  The plan finds the three groups of an x3 config; fp32 results are bit-identical to the unfused walk
+    (same fp32 operations); in bf16 the Add is formed from unrounded sums, so the outputs differ from the unfused walk by roundings
+    only and are no further from the oracle."""
+    g, cfg, model, rgb, ir = load_case([p for p in GOLDEN if p.endswith("s_x3_320.pt")][0])
+    model = model.to(dev).set_compute_dtype(dtype)
+    plan = model.cft_fusion_plan()
+    assert len(plan) == 3 and all(k is not None for (_, _, k) in plan.values())
+    with torch.no_grad():
+        model.fuse_cft_outputs = True
+        pred_f, raw_f = model.forward_once(rgb.to(dev), ir.to(dev))
+        model.overlap_streams = False
+        pred_f1, _ = model.forward_once(rgb.to(dev), ir.to(dev))
+        model.overlap_streams = True
+        model.fuse_cft_outputs = False
+        pred_u, raw_u = model.forward_once(rgb.to(dev), ir.to(dev))
+        model.fuse_cft_outputs = True
+    torch.cuda.synchronize()
+    assert torch.equal(pred_f, pred_f1)                      # one lane or two: same kernels
+    if dtype == torch.float32:
+        assert torch.equal(pred_f, pred_u)
+    else:
+        want_raw = [r for r in g["raw"]]
+        e_f, e_u = _sig_err([r.cpu() for r in raw_f], want_raw), _sig_err([r.cpu() for r in raw_u], want_raw)
+        assert _sig_err([r.cpu() for r in raw_f], [r.cpu() for r in raw_u]) < 2e-2 and e_f <= 1.15 * e_u + 1e-3
+
+
 def test_captured_graph_is_dropped_when_weights_change(dev):
     """a captured graph replays the packed weights of capture time; in-place weight updates,
     load_state_dict and .to()/.half() must not return detections of the old weights."""

@@ -189,6 +189,39 @@ def test_gpt_tokenize_and_upsample(dev, dtype, hw):
     assert rel_err(to_cpu_f32(up0), F.interpolate(m, size=(H, W), mode="bilinear")) < tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
+@pytest.mark.parametrize("hw,C", [((80, 80), 256), ((20, 20), 1024), ((12, 20), 64), ((5, 7), 64), ((40, 40), 1280)])
+def test_gpt_upsample_add_dual(dev, dtype, hw, C):
+    """cft_gpt_upsample_add2 = both streams' de-tokenise + Add2 and the Add behind them in one launch: out0 / out1 are bit-identical
+    to two cft_gpt_upsample_add launches; the sum is formed from the unrounded fp32 sums (one rounding): within half an output ulp of
+    the exact sum, so at least as close to it as add(out0, out1); fp32 is bit-identical to the three-launch path; a channel-slice
+    destination for the sum (the planned concat buffer of the head) works."""
+    from msod_amd import ops
+    H, W = hw
+    B = 2
+    rgb, ir = _q(_rnd(B, C, H, W, seed=19), dtype), _q(_rnd(B, C, H, W, seed=20), dtype)
+    tok = _rnd(B, 128, C, seed=23).to(dev)
+    rd, idv = to_dev_nhwc(rgb, dev, dtype), to_dev_nhwc(ir, dev, dtype)
+    a0 = ops.gpt_upsample_add(tok, 0, rd, H, W, dtype)
+    a1 = ops.gpt_upsample_add(tok, 1, idv, H, W, dtype)
+    three = ops.add(a0, a1)
+    buf = ops.new_nhwc(B, H, W, 2 * C, dtype, dev)
+    buf.zero_()
+    o0, o1, osum = ops.gpt_upsample_add_dual(tok, rd, idv, H, W, dtype, sum_out=buf[:, C:])
+    p0, p1, none = ops.gpt_upsample_add_dual(tok, rd, idv, H, W, dtype, want_sum=False)
+    torch.cuda.synchronize()
+    assert none is None and torch.equal(o0, a0) and torch.equal(o1, a1) and torch.equal(p0, a0) and torch.equal(p1, a1)
+    assert osum.data_ptr() == buf[:, C:].data_ptr() and float(buf[:, :C].abs().max()) == 0.0
+    m = tok.cpu().view(B, 2, 8, 8, C).permute(0, 1, 4, 2, 3)
+    exact = (rgb + F.interpolate(m[:, 0].contiguous(), size=(H, W), mode="bilinear")) + (ir + F.interpolate(m[:, 1].contiguous(), size=(H, W), mode="bilinear"))
+    if dtype == torch.float32:
+        assert torch.equal(osum, three)
+    else:
+        e_dual, e_three = (to_cpu_f32(osum) - exact).abs(), (to_cpu_f32(three) - exact).abs()
+        assert e_dual.max() <= e_three.max() + 1e-6 and e_dual.mean() <= e_three.mean()
+    assert rel_err(to_cpu_f32(osum), exact) < tol(dtype)
+
+
 @pytest.mark.parametrize("C", [64, 256, 320, 1024, 1280])
 def test_layernorm(dev, C):
     from msod_amd import ops
@@ -317,7 +350,7 @@ def test_conv3x3_wide_layers_at_the_benchmarked_row_count(dev, dtype, shape):
     lib = _lib.load()
     outs = {}
     try:
-        for variant in (0, 27, 60, 51, 90, 91):
+        for variant in (0, 27, 60, 51):
             lib.cft_set_conv_variant(variant)
             y = ops.conv2d(xd, pk, 1, residual=rd)
             torch.cuda.synchronize()
@@ -497,8 +530,7 @@ def test_plain_nchw_tensor_into_a_module(dev, dtype):
     assert torch.equal(z[:, :12].float().cpu(), _q(_rnd(2, 12, 5, 7, seed=82), dtype)) and z[:, 12:].abs().max() == 0
 
 
-ALT_VARIANTS = [0, 27, 51, 91]   # (91 = the ring-staged 8-wave 256x256 kernel wherever the layer is eligible)
-# automatic choice / forced big tiles with the uniform-K-walk address path (UNIK) where the layer allows it,
+ALT_VARIANTS = [0, 27, 51]   # automatic choice / forced big tiles with the uniform-K-walk address path (UNIK) where the layer allows it,
 # against variant 900 = the generic per-thread address path
 STAGGERED_CASES = [
     # B, H, W, Cin, Cout, k, s, residual
@@ -544,6 +576,40 @@ def test_alternative_gemm_variants_are_bit_identical(dev, dtype, variant, case):
     got = to_cpu_f32(outs[variant])[:, :Cout]
     if not use_res:
         assert rel_err(got, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
+def test_probe_build_8wave_kernel_is_bit_identical(dev, dtype):
+    """The 8-wave register-double-buffered 256x256 kernel (csrc/conv_ring.hip, probe build only: it is slower than the shipped 16-wave
+    kernel, profiles/r04_gemm_experiments.md) against the generic path of the same library, bit for bit, on the eligible cases above
+    plus a wide layer with two N tiles.  Skipped when libcft_hip_probes.so has not been built (tools/build_probes.sh)."""
+    import os
+    from msod_amd import _lib, ops
+    probes = os.path.join(os.path.dirname(_lib.LIB_PATH), "libcft_hip_probes.so")
+    if not os.path.exists(probes):
+        pytest.skip("probe build absent")
+    saved = (_lib._lib, _lib.LIB_PATH)
+    _lib._lib, _lib.LIB_PATH = None, probes
+    try:
+        lib = _lib.load()
+        for case in [c for c in STAGGERED_CASES if c[3] % 64 == 0] + [(2, 24, 24, 256, 512, 3, 1, True), (1, 40, 40, 512, 256, 1, 1, False)]:
+            B, H, W, Cin, Cout, k, s_, use_res = case
+            x = _q(_rnd(B, Cin, H, W, seed=91), dtype)
+            w = _q(_rnd(Cout, Cin, k, k, seed=92, scale=1.0 / math.sqrt(Cin * k * k)), dtype)
+            pk = ops.pack_conv(w, _rnd(Cout, seed=93, scale=0.5), dtype, s=s_, device=dev)
+            xd = to_dev_nhwc(x, dev, dtype)
+            outs = {}
+            for v in (900, 91):
+                lib.cft_set_conv_variant(v)
+                try:
+                    y0 = ops.conv2d(xd, pk, 1)
+                    outs[v] = ops.conv2d(xd, pk, 1, residual=y0.clone() if use_res else None)
+                    torch.cuda.synchronize()
+                finally:
+                    lib.cft_set_conv_variant(0)
+            assert torch.equal(outs[900], outs[91]), case
+    finally:
+        _lib._lib, _lib.LIB_PATH = saved
 
 
 def test_clock_probe_reports_ticks_and_work(dev):

@@ -273,6 +273,9 @@ def test_bench_parity_check_flags_a_wrong_batch():
     ref16 = [r[:2] for r in noise(0.02)]
     ok = bench.parity_at_bench_shape("bf16", noise(0.02), want, ref16, 2)
     assert ok["ok"] and ok["pairs"] == 4 and ok["vs_reference_style_bf16"]["ok"]
+    assert "NOT the literal 1e-2" in ok["gate"] and ok["meets_north_star_bound"] is False      # bf16 says in words what it is gated on
+    f16 = bench.parity_at_bench_shape("f16", noise(0.002), want)
+    assert f16["meets_north_star_bound"] is True and "parity-green" in f16["gate"]
     assert not bench.parity_at_bench_shape("bf16", noise(0.5), want, ref16, 2)["ok"]             # absolute bound
     worse = bench.parity_at_bench_shape("bf16", noise(0.06), want, ref16, 2)                     # inside 2.5e-2? no - and 3x the reference level
     assert not worse["ok"]

@@ -88,3 +88,63 @@ def test_letterboxed_uint8_pair_feeds_the_model(dev):
     for a, b in zip(raw, want_raw):
         assert (a.cpu() - b).abs().max().item() <= 1e-3
     assert torch.allclose(pred.cpu(), want_pred, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_model_nms_module_and_two_stream_autoshape(dev):
+    """``Model.nms()`` (reference models/yolo_test.py:306-318) and ``Model.autoshape()`` (:320-324, in the two-stream form): the NMS
+    module behind Detect returns what ``non_max_suppression`` returns for the same predictions - eagerly and behind a captured HIP
+    graph; ``autoShape`` on two lists of differently sized RGB-order uint8 images equals the caller-side chain done by hand on the
+    CPU oracles (letterbox to the common stride-rounded shape -> /255 -> fp32 oracle forward -> oracle NMS -> scale_coords)."""
+    from msod_amd.models.common import NMS
+    from msod_amd.models.configs import named_config
+    from msod_amd.models.yolo_test import Model, make_divisible
+    from msod_amd.utils.general import non_max_suppression, scale_coords
+    from msod_amd.utils.seeded import seeded_inputs, seeded_state_dict
+    from oracle.cft_oracle import OracleModel
+    from oracle.nms_oracle import non_max_suppression as nms_oracle
+    cfg = named_config("cfg2")
+    model = Model(cfg)
+    sd = seeded_state_dict(model.state_dict(), 4)
+    model.load_state_dict(sd)
+    model = model.to(dev).set_compute_dtype(torch.float32)
+    rgb, ir = seeded_inputs(2, 128, 160, 9)
+    with torch.no_grad():
+        pred, _ = model(rgb.to(dev), ir.to(dev))
+        want = non_max_suppression(pred, 0.25, 0.45)
+        model.nms()
+        assert type(model.model[-1]) is NMS and model.model[-1].i == len(model.model) - 1
+        got = model(rgb.to(dev), ir.to(dev))
+        model.capture(2, 128, 160)
+        got_graph = model(rgb.to(dev), ir.to(dev))
+        model.nms(False)
+        assert type(model.model[-1]) is not NMS
+        again, _ = model(rgb.to(dev), ir.to(dev))
+    assert sum(len(w) for w in want) > 0 and torch.equal(again, pred)
+    for a, b, c in zip(got, got_graph, want):
+        assert torch.equal(a, c) and torch.equal(b, c)
+    model._print_biases()
+
+    rng = np.random.RandomState(11)
+    sizes = [(150, 200), (96, 128)]
+    ims_rgb = [rng.randint(0, 256, s + (3,)).astype(np.uint8) for s in sizes]
+    ims_ir = [rng.randint(0, 256, s + (3,)).astype(np.uint8) for s in sizes]
+    wrapped = model.autoshape()
+    wrapped.conf = 0.25
+    out = wrapped(ims_rgb, ims_ir, size=128)
+    # by hand, on the oracles
+    shape1 = [make_divisible(max(s[d] * (128 / max(s)) for s in sizes), 32) for d in (0, 1)]
+    planes = []
+    for a, b in zip(ims_rgb, ims_ir):
+        la, _, _ = _oracle_letterbox(a, new_shape=shape1, auto=False)
+        lb, _, _ = _oracle_letterbox(b, new_shape=shape1, auto=False)
+        planes.append(np.concatenate([la.transpose(2, 0, 1), lb.transpose(2, 0, 1)], 0))
+    f = torch.from_numpy(np.stack(planes, 0)).float() / 255.0
+    want_pred, _ = OracleModel(cfg)(sd, f[:, :3], f[:, 3:])
+    ref = nms_oracle(want_pred, 0.25, 0.45)
+    assert len(out) == 2
+    for i, (o, r) in enumerate(zip(out, ref)):
+        r = r.clone()
+        scale_coords(shape1, r[:, :4], sizes[i])
+        assert o.shape == r.shape, (o.shape, r.shape)
+        assert torch.allclose(o.cpu(), r, rtol=1e-3, atol=2e-2)

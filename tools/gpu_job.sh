@@ -102,7 +102,29 @@ PY
     ARGS="--in-flight 2 --steps 200"; run "kernarg=0" HIP_FORCE_DEV_KERNARG=0
     ARGS="--in-flight 2 --steps 200"; run "kernarg=1" HIP_FORCE_DEV_KERNARG=1
     ARGS="--in-flight 2 --conv-variant 90"; run "ring kernel (variant 90) on the wide layers, 2 in flight" A=1
-    ARGS="--in-flight 2"; run "default again" A=1 ;;
+    ARGS="--in-flight 2"; run "default again" A=1
+    timeout 600 python -m pytest tests/test_gpu_distributed.py -q -m gpu -x > $O/dist_tests.log 2>&1; echo "rccl world-size-1 tests rc=$?" | tee -a $O/summary.txt; tail -4 $O/dist_tests.log
+    timeout 300 python bench.py $X --in-flight 2 --force-gather > $O/bench_force_gather.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/bench_force_gather.json'));print('force-gather', d['value'], d['ms_per_step'], d['multi_gpu_selfcheck'])" | tee -a $O/summary.txt ;;
+  r4b)         # round 4: the 8-wave full-line GEMM kernel (variants 90 / 91): bit-identity, per-shape A/B, probes, whole-forward A/B
+    timeout 900 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "alternative_gemm or wide_layers" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -4 $O/tests.log
+    WIDE="3x3s2 128->256|C3 1x1 256->256|3x3s2 256->512|C3 1x1 512->512|bneck 1x1 256->256|bneck 3x3 256->256|3x3s2 512->1024|bneck 3x3 512->512|1x1 1024->1024|SPP cv2|GPT|quant"
+    timeout 600 python tools/gemm_bench.py --variants 0,91 --only "$WIDE" --rounds 3 --out $JOB/gemm_ab.json > $O/gemm.log 2>&1; echo "gemm rc=$?" | tee -a $O/summary.txt
+    python - <<PY
+import json
+for r in json.load(open("gpurun_out/$JOB/gemm_ab.json")):
+    v = r["variants"]
+    print(f'{r["shape"]:42s} auto {v["0"]["us"]:7.1f} us {v["0"]["tflops"]:7.1f} TF | 8-wave {v["91"]["us"]:7.1f} us {v["91"]["tflops"]:7.1f} TF  diff {v["91"]["maxdiff_vs_first"]}')
+PY
+    if [ -f multispectral-object-detection_amd/libcft_hip_probes.so ]; then
+      timeout 600 python tools/gemm_bench.py --lib multispectral-object-detection_amd/libcft_hip_probes.so --variants 27,127,227,1627,91,190,290,1690 --only "bneck 3x3 256->256|GPT fc1 1024|C3 1x1 512->512|quant 3x3" --rounds 3 --out $JOB/gemm_probes.json > $O/probes.log 2>&1; echo "probes rc=$?" | tee -a $O/summary.txt
+      python - <<PY
+import json
+for r in json.load(open("gpurun_out/$JOB/gemm_probes.json")):
+    print(r["shape"], {k: v.get("us") for k, v in r["variants"].items()})
+PY
+    fi
+    X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
+    for v in 0 90 0 90; do timeout 300 python bench.py $X --conv-variant $v > $O/bench_v$v.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/bench_v$v.json'));print('variant $v', d['value'], d['ms_per_step'], d['single_in_flight']['value'], d['roofline']['frac'])" | tee -a $O/summary.txt; done ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
