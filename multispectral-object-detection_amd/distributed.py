@@ -256,14 +256,16 @@ class ForwardPipeline:
             raise ValueError("one stream per runner")
 
     @staticmethod
-    def pick_streams(runners, device, groups=4, probe_steps=6):
+    def pick_streams(runners, device, groups=4, probe_steps=6, priorities=None):
         """HIP maps streams onto a few hardware queues, and a captured forward brings internal branch streams of its own: which
         streams the forwards in flight are replayed on changes the steady-state rate by up to 8 % (two attractors, measured:
         profiles/r03_forwards_in_flight.txt).  This draws ``groups`` candidate groups of K streams, times ``probe_steps`` steps per
-        forward on each and returns the fastest group (plus the measured table)."""
+        forward on each and returns the fastest group (plus the measured table).  ``priorities``: optional HIP stream priority per
+        forward; round 4 measured (-1, 0) and (-1, -1) SLOWER than the default equal priorities (profiles/r04_forwards_in_flight.txt)."""
         k = len(runners)
         torch.cuda.synchronize(device)      # the runners' inputs (written on the caller's stream) are complete before any probe replays them
-        cands = [[torch.cuda.Stream(device=device) for _ in range(k)] for _ in range(groups)]
+        pr = list(priorities) if priorities is not None else [0] * k      # optional HIP stream priority per forward in flight (-1 = high)
+        cands = [[torch.cuda.Stream(device=device, priority=pr[i % len(pr)]) for i in range(k)] for _ in range(groups)]
         table = []
         for streams in cands:
             pipe = ForwardPipeline(runners, streams)

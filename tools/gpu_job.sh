@@ -125,6 +125,23 @@ PY
     fi
     X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
     for v in 0 90 0 90; do timeout 300 python bench.py $X --conv-variant $v > $O/bench_v$v.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/bench_v$v.json'));print('variant $v', d['value'], d['ms_per_step'], d['single_in_flight']['value'], d['roofline']['frac'])" | tee -a $O/summary.txt; done ;;
+  r4c)         # round 4: new tests (dual de-tokeniser, fusion plan, NMS module / autoShape, RCCL world size 1, probe-build 8-wave kernel), fusion A/B, stream priorities, small-batch in-flight sweep, cfg5
+    timeout 1200 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py tests/test_letterbox.py tests/test_gpu_distributed.py -q -m gpu -x -k "upsample_add_dual or probe_build or cft_output_fusion or nms_module or rccl or sharded_detect or tokenize or two_forwards" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -5 $O/tests.log
+    X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
+    run() { tag=$1; shift; timeout 300 python bench.py $X "$@" > $O/b.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/b.json'));print('$tag', d['value'], d['ms_per_step'], (d.get('single_in_flight') or {}).get('value'), d['roofline']['whole_step']['frac'], d['config'].get('stream_group_probe_ms_per_step'))" | tee -a $O/summary.txt; }
+    run "fused CFT outputs (default)"
+    run "three launches (--no-cft-fusion)" --no-cft-fusion
+    run "fused CFT outputs (default)"
+    run "three launches (--no-cft-fusion)" --no-cft-fusion
+    run "stream priorities -1,0" --stream-priorities=-1,0
+    run "stream priorities -1,-1" --stream-priorities=-1,-1
+    run "bs8 in-flight 2" --batch 8 --in-flight 2
+    run "bs8 in-flight 4" --batch 8 --in-flight 4
+    run "bs8 in-flight 6" --batch 8 --in-flight 6
+    run "bs8 in-flight 8" --batch 8 --in-flight 8
+    run "bs16 in-flight 4" --batch 16 --in-flight 4
+    run "cfg5 16 pairs 1280 in-flight 2" --config cfg5 --batch 16 --size 1280 --in-flight 2
+    run "cfg5 16 pairs 1280 in-flight 3" --config cfg5 --batch 16 --size 1280 --in-flight 3 ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
