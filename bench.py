@@ -409,7 +409,14 @@ def main():
         cft_ms = lin["ms"] + sum(v[2] for v in aux.values()) * 1e3
         cft_block = None
         if cft_ms > 0:
+            cft_bytes = sum(v[3] for k, v in fam.items() if k.startswith("linear")) + sum(v[3] for v in aux.values())
+            cft_mfma_ms, cft_hbm_ms = cft_flops / (peak * 1e12) * 1e3, cft_bytes / (HBM_ACHIEVABLE_TBPS * 1e12) * 1e3
             cft_block = {"tflops": round(cft_flops / cft_ms / 1e9, 1), "frac": round(cft_flops / cft_ms / 1e9 / peak, 4), "ms": round(cft_ms, 3),
+                         # what the block's own FLOPs and bytes allow: with 128 tokens per image the attention core has 64 FLOP per byte and the
+                         # d = 256 / 512 linears 150 - 400, against a machine balance of ~400 FLOP/B - most of the block is HBM-bound by roofline
+                         "floors": {"mfma_ms": round(cft_mfma_ms, 3), "hbm_ms_algorithmic": round(cft_hbm_ms, 3),
+                                    "max_frac_of_mfma_peak_if_both_overlap_perfectly": round(cft_mfma_ms / max(cft_mfma_ms, cft_hbm_ms), 4),
+                                    "max_frac_if_they_add": round(cft_mfma_ms / (cft_mfma_ms + cft_hbm_ms), 4)},
                          "launches": sum(v[0] for k, v in fam.items() if k.startswith("linear")) + sum(v[0] for v in aux.values()),
                          "parts_ms": {"linears": lin["ms"], **{k[4:]: round(v[2] * 1e3, 3) for k, v in aux.items()}}}
         line = {

@@ -142,13 +142,17 @@ PY
     run "bs16 in-flight 4" --batch 16 --in-flight 4
     run "cfg5 16 pairs 1280 in-flight 2" --config cfg5 --batch 16 --size 1280 --in-flight 2
     run "cfg5 16 pairs 1280 in-flight 3" --config cfg5 --batch 16 --size 1280 --in-flight 3 ;;
+  r4d)         # round 4: full -m gpu suite + smoke + the default bench line (format check of the new fields)
+    timeout 2400 python -m pytest tests -q -m gpu -x > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -5 $O/tests.log
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/summary.txt; tail -3 $O/smoke.log
+    timeout 900 python bench.py > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee -a $O/summary.txt; tail -2 $O/bench.log; head -c 3000 $O/bench.json ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
   evidence)    # PMC traffic passes, bench line, rocprofv3 kernel stats (single- and two-stream)
     bash tools/pmc_traffic.sh $O/traffic > $O/traffic.log 2>&1
     python tools/traffic_summary.py $O/traffic $O/traffic.json config=cfg3 batch=64 size=640 dtype=bf16 | tee $O/summary.txt
-    rm -rf $O/traffic; cp $O/traffic.json profiles/r03_traffic.json
+    rm -rf $O/traffic; cp $O/traffic.json profiles/r04_traffic.json
     timeout 900 python bench.py > $O/bench_bs64.json 2> $O/bench.log; echo "bench rc=$?" | tee -a $O/summary.txt
     cp gpurun_out/bench_families.json $O/gemm_families_cfg3.json
     timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof1 --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f16-leg --no-overlap --in-flight 1 --sustained-steps 0 --no-parity > $O/prof1.log 2>&1; echo "prof single-stream rc=$?" | tee -a $O/summary.txt
