@@ -150,6 +150,7 @@ PY
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
   evidence)    # PMC traffic passes, bench line, rocprofv3 kernel stats (single- and two-stream)
+    timeout 120 tools/micro/power_coupling > $O/power_coupling.txt 2>&1; cat $O/power_coupling.txt
     bash tools/pmc_traffic.sh $O/traffic > $O/traffic.log 2>&1
     python tools/traffic_summary.py $O/traffic $O/traffic.json config=cfg3 batch=64 size=640 dtype=bf16 | tee $O/summary.txt
     rm -rf $O/traffic; cp $O/traffic.json profiles/r04_traffic.json
