@@ -591,7 +591,13 @@ def test_probe_build_8wave_kernel_is_bit_identical(dev, dtype):
     saved = (_lib._lib, _lib.LIB_PATH)
     _lib._lib, _lib.LIB_PATH = None, probes
     try:
-        lib = _lib.load()
+        try:
+            lib = _lib.load()
+            stale = lib.cft_abi_version() != _lib.ABI_VERSION
+        except AttributeError:          # built from older sources: an export is missing
+            stale = True
+        if stale:
+            pytest.skip("probe build is older than the product library (re-run tools/build_probes.sh)")
         for case in [c for c in STAGGERED_CASES if c[3] % 64 == 0] + [(2, 24, 24, 256, 512, 3, 1, True), (1, 40, 40, 512, 256, 1, 1, False)]:
             B, H, W, Cin, Cout, k, s_, use_res = case
             x = _q(_rnd(B, Cin, H, W, seed=91), dtype)

@@ -146,6 +146,16 @@ PY
     timeout 2400 python -m pytest tests -q -m gpu -x > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -5 $O/tests.log
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/summary.txt; tail -3 $O/smoke.log
     timeout 900 python bench.py > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee -a $O/summary.txt; tail -2 $O/bench.log; head -c 3000 $O/bench.json ;;
+  pmc4)        # round 4: PMC counters of the shipped 16-wave kernel (27) and the probe build's 8-wave kernel (91) on 3x3 256->256 @40 (+res)
+    for v in 27 91; do
+      bash tools/pmc.sh $O/v$v -- python tools/gemm_bench.py --lib multispectral-object-detection_amd/libcft_hip_probes.so --variants $v --iters 10 --rounds 1 --only "bneck 3x3 256->256" --out $JOB/g$v.json > $O/pmc_v$v.log 2>&1
+      python tools/pmc_summary.py $O/v$v conv_gemm > $O/pmc_3x3_256ch_40x40_variant$v.txt; rm -rf $O/v$v
+      head -32 $O/pmc_3x3_256ch_40x40_variant$v.txt
+    done ;;
+  micro4)      # round 4 micro-benchmarks: HBM read / write / copy ceilings; DMA stream coupled with fragment reads / MFMAs; power coupling
+    timeout 120 tools/micro/hbm_rw > $O/hbm_rw.txt 2>&1; cat $O/hbm_rw.txt
+    timeout 200 tools/micro/dma_ring > $O/dma_ring.txt 2>&1; grep -A20 "coupling of the DMA" $O/dma_ring.txt
+    timeout 120 tools/micro/power_coupling > $O/power_coupling.txt 2>&1; cat $O/power_coupling.txt ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;

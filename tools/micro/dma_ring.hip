@@ -14,7 +14,15 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // ROWB: bytes per staged row; STAGE_KIB: bytes of one stage; DEPTH: stages kept in flight; SRC: 0 = a 256-row weight-like matrix shared by
 // every workgroup (row stride 4608 B: L2 hits), 1 = activation-like rows private to the workgroup, streamed from HBM (row stride 512 B, every
 // byte read once), 2 = half the loads of each kind (what a GEMM K step stages); BAR: raw s_barrier per stage (couples the 8 waves).
-template <int ROWB, int STAGE_KIB, int DEPTH, int SRC, bool BAR>
+// WORK (round 4, second question: what couples the DMA stream and the matrix side of a GEMM K loop?): 0 = the stream alone; 1 = every wave
+// also reads the stage that has landed the way a 128 x 64 wave tile reads its fragments (12 ds_read_b128 per 32 KiB staged: 3 bytes read
+// per byte staged); 2 = every wave also issues the K step's MFMAs (32 per 32 KiB staged, operands in registers, no LDS reads);
+// 3 = both - a GEMM K loop without its epilogue.  Compare the bytes per second of 1 / 2 / 3 with 0, and the time per 64 KiB with 2's alone.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+template <int ROWB, int STAGE_KIB, int DEPTH, int SRC, bool BAR, int WORK = 0>
 __global__ void __launch_bounds__(512) dma_kernel(const unsigned char* w, const unsigned char* x, int nsteps, long x_rows_per_wg, int* sink) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE = STAGE_KIB * 1024;
@@ -33,6 +41,15 @@ __global__ void __launch_bounds__(512) dma_kernel(const unsigned char* w, const 
     wsrc[i] = w + (long)(row & 255) * 4608 + g * 16 + (row >> 8) * 2304;
     xsrc[i] = x + ((long)blockIdx.x * x_rows_per_wg + row) * 512 + g * 16;
   }
+  f32x4_t acc[32];
+  u32x4_t fr[12];
+  if constexpr (WORK != 0) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 12; ++i) fr[i] = u32x4_t{0x3f803f80u + (unsigned)lane * 77u + i, 0x3f903fa0u ^ (unsigned)(tid << 3), 0xbf803f00u + i * 5u, 0x3f003f40u};
+  }
+  const unsigned rd_base = (unsigned)(lane & 15) * ROWB + (unsigned)(((lane >> 4) ^ (lane & 7)) << 4);
   int wk = 0;            // byte offset of the k chunk inside a weight row
   long xk = 0;           // byte offset of the chunk inside the private rows
   int xc = 0;
@@ -42,26 +59,56 @@ __global__ void __launch_bounds__(512) dma_kernel(const unsigned char* w, const 
     for (int i = 0; i < LPS; ++i) {
       const bool from_w = SRC == 0 || (SRC == 2 && (i & 1));
       const unsigned char* src = from_w ? wsrc[i] + wk : xsrc[i] + xk;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(smem + slot * STAGE + i * 8192 + wave * 1024), 16, 0, 0);
+      if constexpr (!(WORK & 4))        // WORK bit 2: no DMA at all (the matrix side alone, on whatever the LDS holds)
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(smem + slot * STAGE + i * 8192 + wave * 1024), 16, 0, 0);
     }
     wk += ROWB; if (wk >= 2304) wk = 0;
     xk += ROWB; xc += ROWB;
     if (xc == 512) { xc = 0; xk += (long)(LPS * RPP) * 512 - 512; }     // next block of private rows
     if constexpr (DEPTH == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS * (DEPTH - 1)) : "memory");
-    if constexpr (BAR) asm volatile("s_barrier" ::: "memory");
+    if constexpr (BAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (WORK != 0) {           // the stage that has just been waited for (s - DEPTH + 1) is complete in every wave
+      constexpr int REP = STAGE / 32768 > 0 ? STAGE / 32768 : 1;        // per 32 KiB staged: 12 reads / 32 MFMAs per wave
+      const int done = (s + NSLOT - (DEPTH - 1)) % NSLOT;
+#pragma unroll
+      for (int rep = 0; rep < REP; ++rep) {
+        if constexpr (WORK & 1) {
+          const unsigned a0 = (unsigned)(done * STAGE) + (unsigned)(wave & 1) * 8192u + rd_base + rep * 16384u;
+#pragma unroll
+          for (int i = 0; i < 12; ++i)
+            fr[i] = *reinterpret_cast<const u32x4_t*>(smem + ((a0 + (unsigned)i * (16u * ROWB)) % (unsigned)STAGE) + 0u);
+        }
+        if constexpr (WORK & 2) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fr[i]), __builtin_bit_cast(bf16x8_t, fr[8 + j]), acc[i * 4 + j], 0, 0, 0);
+        } else if constexpr (WORK & 1) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) asm volatile("" ::"v"(fr[i]));
+        }
+      }
+    }
+  }
+  if constexpr (WORK & 2) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) sacc += acc[i][0] + acc[i][3];
+    if (sink != nullptr && sacc == 1.2345f) sink[tid] = 2;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (sink != nullptr && smem[tid * 16] == 123 && nsteps < 0) sink[tid] = 1;
 }
 
-template <int ROWB, int STAGE_KIB, int DEPTH, int SRC, bool BAR>
+template <int ROWB, int STAGE_KIB, int DEPTH, int SRC, bool BAR, int WORK = 0>
 static void run(const unsigned char* w, const unsigned char* x, long xbytes, int ncu) {
   constexpr int STAGE = STAGE_KIB * 1024;
   const int smem = (DEPTH + 1) * STAGE;
   if (smem > 160 * 1024) return;
-  auto k = dma_kernel<ROWB, STAGE_KIB, DEPTH, SRC, BAR>;
+  auto k = dma_kernel<ROWB, STAGE_KIB, DEPTH, SRC, BAR, WORK>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   constexpr int LPS = STAGE / 8192, RPP = 512 / (ROWB / 16);
   const long rows_per_block = (long)LPS * RPP;                      // private rows consumed per 512 / ROWB stages
@@ -78,8 +125,8 @@ static void run(const unsigned char* w, const unsigned char* x, long xbytes, int
     if (rep > 0 && ms < best) best = ms;
   }
   const double bytes = (double)ncu * nsteps * STAGE;
-  printf("rows %3d B  stage %2d KiB  depth %d (%3d KiB in flight)  src %d  barrier %d : %7.1f GB/s per CU  %6.2f TB/s chip  %.3f us per 64 KiB\n",
-         ROWB, STAGE_KIB, DEPTH, DEPTH * STAGE_KIB, SRC, (int)BAR, bytes / ncu / (best * 1e-3) / 1e9, bytes / (best * 1e-3) / 1e12,
+  printf("rows %3d B  stage %2d KiB  depth %d (%3d KiB in flight)  src %d  barrier %d  work %d : %7.1f GB/s per CU  %6.2f TB/s chip  %.3f us per 64 KiB\n",
+         ROWB, STAGE_KIB, DEPTH, DEPTH * STAGE_KIB, SRC, (int)BAR, WORK, bytes / ncu / (best * 1e-3) / 1e9, bytes / (best * 1e-3) / 1e12,
          best * 1e3 / nsteps * (65536.0 / STAGE));
   hipEventDestroy(e0); hipEventDestroy(e1);
 }
@@ -103,6 +150,14 @@ static void sweep(const unsigned char* w, const unsigned char* x, long xbytes, i
   run<64, 16, 8, SRC, BAR>(w, x, xbytes, ncu);
 }
 
+// operands with full-range mantissas and mixed signs, exponents near 1: zero or constant data lets the chip clock higher (guide 5.4 rule 25)
+__global__ void fill_bf16(unsigned* p, long n_words) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (long)gridDim.x * 256) {
+    unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (h & 0x807f807fu) | 0x3f003f00u | ((h >> 3) & 0x00800080u);
+  }
+}
+
 int main() {
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
   const int ncu = p.multiProcessorCount;
@@ -110,12 +165,22 @@ int main() {
   unsigned char *w, *x;
   const long wbytes = 4 << 20, xbytes = 6L << 30;
   hipMalloc(&w, wbytes); hipMalloc(&x, xbytes);
-  hipMemset(w, 1, wbytes); hipMemset(x, 2, xbytes);
+  hipLaunchKernelGGL(fill_bf16, dim3(1024), dim3(256), 0, 0, (unsigned*)w, wbytes / 4);
+  hipLaunchKernelGGL(fill_bf16, dim3(8192), dim3(256), 0, 0, (unsigned*)x, xbytes / 4);
   hipDeviceSynchronize();
   printf("== weight-like source (shared, L2 hits) ==\n");      sweep<0, true>(w, x, xbytes, ncu);
   printf("== activation-like source (private, HBM stream) ==\n"); sweep<1, true>(w, x, xbytes, ncu);
   printf("== half / half (a GEMM K step) ==\n");                sweep<2, true>(w, x, xbytes, ncu);
   printf("== half / half, no barrier ==\n");                    sweep<2, false>(w, x, xbytes, ncu);
+  printf("== coupling of the DMA stream with the matrix side (weight-like source: everything hits L2; work 1 = fragment reads, 2 = MFMAs, 3 = both) ==\n");
+  run<128, 32, 2, 0, true, 0>(w, x, xbytes, ncu); run<128, 32, 2, 0, true, 1>(w, x, xbytes, ncu);
+  run<128, 32, 2, 0, true, 2>(w, x, xbytes, ncu); run<128, 32, 2, 0, true, 3>(w, x, xbytes, ncu);
+  printf("   (work 5 / 6 / 7 = fragment reads / MFMAs / both WITHOUT the DMA stream: GB/s then means staged-bytes-equivalent per second)\n");
+  run<128, 32, 2, 0, true, 5>(w, x, xbytes, ncu); run<128, 32, 2, 0, true, 6>(w, x, xbytes, ncu); run<128, 32, 2, 0, true, 7>(w, x, xbytes, ncu);
+  run<128, 64, 1, 0, true, 0>(w, x, xbytes, ncu); run<128, 64, 1, 0, true, 1>(w, x, xbytes, ncu);
+  run<128, 64, 1, 0, true, 2>(w, x, xbytes, ncu); run<128, 64, 1, 0, true, 3>(w, x, xbytes, ncu);
+  printf("== the same with the GEMM mix of sources (half from L2, half streamed from HBM) ==\n");
+  run<128, 32, 2, 2, true, 0>(w, x, xbytes, ncu); run<128, 32, 2, 2, true, 2>(w, x, xbytes, ncu); run<128, 32, 2, 2, true, 3>(w, x, xbytes, ncu);
   hipFree(w); hipFree(x);
   return 0;
 }
