@@ -21,6 +21,8 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+// WORK bit 3 (8): the same FLOPs as 32x32x16 MFMAs (16 per 32 KiB staged: a 128 x 64 wave tile = 4 x 2 tiles of 32 x 32, two 16-wide k chunks)
 
 template <int ROWB, int STAGE_KIB, int DEPTH, int SRC, bool BAR, int WORK = 0>
 __global__ void __launch_bounds__(512) dma_kernel(const unsigned char* w, const unsigned char* x, int nsteps, long x_rows_per_wg, int* sink) {
@@ -42,10 +44,15 @@ __global__ void __launch_bounds__(512) dma_kernel(const unsigned char* w, const 
     xsrc[i] = x + ((long)blockIdx.x * x_rows_per_wg + row) * 512 + g * 16;
   }
   f32x4_t acc[32];
+  f32x16_t acc32[8];
   u32x4_t fr[12];
   if constexpr (WORK != 0) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc32[i][e] = 0.f;
 #pragma unroll
     for (int i = 0; i < 12; ++i) fr[i] = u32x4_t{0x3f803f80u + (unsigned)lane * 77u + i, 0x3f903fa0u ^ (unsigned)(tid << 3), 0xbf803f00u + i * 5u, 0x3f003f40u};
   }
@@ -79,7 +86,15 @@ __global__ void __launch_bounds__(512) dma_kernel(const unsigned char* w, const 
           for (int i = 0; i < 12; ++i)
             fr[i] = *reinterpret_cast<const u32x4_t*>(smem + ((a0 + (unsigned)i * (16u * ROWB)) % (unsigned)STAGE) + 0u);
         }
-        if constexpr (WORK & 2) {
+        if constexpr ((WORK & 2) && (WORK & 8)) {
+#pragma unroll
+          for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc32[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fr[kc * 4 + i]), __builtin_bit_cast(bf16x8_t, fr[8 + kc * 2 + j]), acc32[i * 2 + j], 0, 0, 0);
+        } else if constexpr (WORK & 2) {
 #pragma unroll
           for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -96,6 +111,8 @@ __global__ void __launch_bounds__(512) dma_kernel(const unsigned char* w, const 
     float sacc = 0.f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) sacc += acc[i][0] + acc[i][3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sacc += acc32[i][0] + acc32[i][15];
     if (sink != nullptr && sacc == 1.2345f) sink[tid] = 2;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -177,6 +194,9 @@ int main() {
   run<128, 32, 2, 0, true, 2>(w, x, xbytes, ncu); run<128, 32, 2, 0, true, 3>(w, x, xbytes, ncu);
   printf("   (work 5 / 6 / 7 = fragment reads / MFMAs / both WITHOUT the DMA stream: GB/s then means staged-bytes-equivalent per second)\n");
   run<128, 32, 2, 0, true, 5>(w, x, xbytes, ncu); run<128, 32, 2, 0, true, 6>(w, x, xbytes, ncu); run<128, 32, 2, 0, true, 7>(w, x, xbytes, ncu);
+  printf("   (work + 8: the same FLOPs as 32x32x16 MFMAs; 14 / 15 = MFMAs / reads + MFMAs without the stream, 10 / 11 with it)\n");
+  run<128, 32, 2, 0, true, 14>(w, x, xbytes, ncu); run<128, 32, 2, 0, true, 15>(w, x, xbytes, ncu);
+  run<128, 32, 2, 0, true, 10>(w, x, xbytes, ncu); run<128, 32, 2, 0, true, 11>(w, x, xbytes, ncu);
   run<128, 64, 1, 0, true, 0>(w, x, xbytes, ncu); run<128, 64, 1, 0, true, 1>(w, x, xbytes, ncu);
   run<128, 64, 1, 0, true, 2>(w, x, xbytes, ncu); run<128, 64, 1, 0, true, 3>(w, x, xbytes, ncu);
   printf("== the same with the GEMM mix of sources (half from L2, half streamed from HBM) ==\n");
