@@ -306,3 +306,27 @@ def test_shader_clock_summary_arithmetic():
     assert abs(s["fma_rate_vs_idle"] - 400.0 / 450.0) < 1e-3
     pr.n = 0
     assert pr.summary() is None
+
+
+def test_cft_fusion_plan_and_nms_module_structure():
+    """Host side of round 4's graph-level pieces (no GPU): ``Model.cft_fusion_plan`` finds the (Add2, Add2, Add) group behind every GPT
+    block of an x3 config - the yaml rows reference models/transformer/yolov5l_fusion_transformerx3_FLIR_aligned.yaml wires as
+    [4,10]/[9,10] -> 29, [14,17]/[16,17] -> 30, [22,26]/[25,26] -> 31 - and nothing in a config without GPT blocks; ``Model.nms()``
+    appends / removes the reference's NMS module (models/yolo_test.py:306-318) and ``autoshape()`` wraps the model."""
+    from msod_amd.models.common import NMS, autoShape
+    from msod_amd.models.configs import named_config
+    from msod_amd.models.yolo_test import Model
+    m = Model(named_config("cfg3"))
+    assert m.cft_fusion_plan() == {11: (10, 12, 29), 18: (17, 19, 30), 27: (26, 28, 31)}
+    assert Model(named_config("cfg1")).cft_fusion_plan() == {}
+    n = len(m.model)
+    m.nms()
+    assert len(m.model) == n + 1 and type(m.model[-1]) is NMS and m.model[-1].f == -1 and m.model[-1].i == n
+    assert m.cft_fusion_plan() == {11: (10, 12, 29), 18: (17, 19, 30), 27: (26, 28, 31)}      # re-derived after the structural change
+    m.nms()                                        # idempotent
+    assert len(m.model) == n + 1
+    m.nms(False)
+    assert len(m.model) == n and type(m.model[-1]) is not NMS
+    w = m.autoshape()
+    assert isinstance(w, autoShape) and w.autoshape() is w and w.names == m.names and torch.equal(w.stride, m.stride)
+    m._print_biases()
