@@ -272,6 +272,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--no-concat-plan", action="store_true", help="A/B: let Concat copy all its sources")
+    ap.add_argument("--no-conv-chain", action="store_true", help="A/B: the stride-2 Conv in front of a C3 and the C3's cv1|cv2 as two launches (round 3) instead of one")
     ap.add_argument("--no-cft-fusion", action="store_true", help="A/B: de-tokenise + Add2 per stream and Add as three launches (round 3) instead of one")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-f16-leg", action="store_true", help="skip the extra fp16 measurement (N = 1, 16-bit runs only)")
@@ -307,6 +308,7 @@ def main():
     model.overlap_streams = not args.no_overlap
     model.plan_concats = not args.no_concat_plan
     model.fuse_cft_outputs = not args.no_cft_fusion
+    model.chain_convs = not args.no_conv_chain
     rgb, ir = seeded_inputs(args.batch, args.size, args.size, seed=rank)
     rgb, ir = rgb.to(dev), ir.to(dev)
 

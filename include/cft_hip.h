@@ -67,6 +67,21 @@ int cft_conv2d(const void* x, const void* w, const float* bias, const void* res,
                int act, int dtype, int out_dtype, int res_dtype, void* stream);
 
 /*
+ * Two layers in one launch: a Conv (models/common.py:45-50, SiLU) and the pointwise Conv(s) that consume its output - in the CFT
+ * networks the stride-2 Conv in front of a C3 and that C3's cv1 | cv2 (models/common.py:141-143, both read the same input and are
+ * packed as one [n2][n1] weight).  y = act2(conv1x1(SiLU(conv(x)))):  the first layer's output tile is rounded to dtype in LDS and
+ * becomes the second GEMM's A operand, so the n1-channel tensor between the layers is never written or read.  Results are
+ * bit-identical to the two cft_conv2d launches.  x / w1 / bias1 / geometry as cft_conv2d; w2: dtype [n2][n1] (k = 1), bias2
+ * float[n2] or NULL; y: dtype, ldy / yoff.  Eligible pairs only (cft_conv2d_chain_ok returns 1): bf16 / fp16, n1 == 128,
+ * cin % 64 == 0, kpad1 == k*k*cin, n2 <= 128; anything else is CFT_EINVAL.
+ */
+int cft_conv2d_chain(const void* x, const void* w1, const float* bias1, const void* w2, const float* bias2, void* y,
+                     int B, int H, int W, int cin, int ldx, int xoff,
+                     int n1, int kpad1, int ksize, int stride, int n2,
+                     int ldy, int yoff, int act2, int dtype, void* stream);
+int cft_conv2d_chain_ok(int B, int H, int W, int cin, int n1, int kpad1, int ksize, int stride, int n2, int dtype);
+
+/*
  * Bottleneck as one kernel (models/common.py:99-109 with e = 1.0, the form C3 uses :138):
  *   y = (shortcut ? x : 0) + SiLU(conv3x3(SiLU(conv1x1(x) + b1)) + b2),  c -> c -> c channels, 16-bit dtype.
  * x, y: NHWC channel slices (ldx/xoff, ldy/yoff) that must not overlap (the kernel reads a halo of x);

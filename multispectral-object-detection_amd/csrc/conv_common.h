@@ -16,6 +16,9 @@ struct ConvParams {
   int KS, stride, pad;
   int act, out_f32, res_f32;
   int M, tilesN;
+  const unsigned char* w2;   // chained pointwise layer (conv_gemm_kernel CHAIN): packed weights [N2][N], bias, width; y/ldy/yoff/act are ITS output
+  const float* bias2;
+  int N2;
   long x_bytes, w_bytes;   // extent of the input tensor (B*H*W*ldx elements) and of the packed weights (N*Kpad), in bytes
   uint32_t wo_mul, wo_sh, ho_mul, ho_sh;   // exact n / Wo and n / Ho for n < 2^31 as umulhi(n, mul) >> sh (mul == 0: divisor 1)
 };

@@ -38,7 +38,13 @@
 // chunk) in a K step, so the walk over taps / chunks is SCALAR (SGPR) arithmetic and a thread only keeps constant pointers:
 // the staging block shrinks from ~80 to ~25 instructions per K step (16 waves issue it in lock step after every barrier,
 // with the matrix pipe idle).  Same fetches, same LDS image, same products and k order: bit-identical to the generic path.
-template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0, bool UNIK = false>
+// CHAIN (needs GLDS, one N tile, N == 2 K steps): a second, pointwise GEMM runs on the tile before anything is stored - the
+// stride-2 Conv in front of a C3 and that C3's packed cv1|cv2 (both consume exactly this tile's pixels).  After the K loop the
+// accumulators get the first layer's bias + activation + rounding and are written to LDS AS the second GEMM's A tile (same
+// swizzled [row][64 k] images the staging buffers held; the k-th image = channels 64k..64k+63), the second layer's weights are
+// fetched into the B buffers, and the same fragment reads / MFMAs walk the two images.  Same values, same roundings, same k
+// order as the two launches; the intermediate tensor (M x N elements written, then read) never exists.
+template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0, bool UNIK = false, bool CHAIN = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvParams p) {
   constexpr int NTHR = 64 * WGM * WGN;
   constexpr int GE = Elem<T>::GE;
@@ -220,6 +226,26 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
   }
   int u_ci = 0;                                  // scalar: channel offset of the K step inside its tap (tap-major walk)
 
+// The two 32-wide k sub-steps of one staged K step: fragment reads + MFMAs of LDS buffer buf_.
+#define CFT_COMPUTE_STEP(buf_)                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                   \
+    const int kg = ks * 4 + lgrp;                                                                      \
+    gran_t af[MT], bf[NT];                                                                             \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                   \
+      const int row = wm * WM + i * 16 + lrow;                                                         \
+      af[i] = *reinterpret_cast<const gran_t*>(sA + (buf_) * A_BYTES + row * 128 + ((kg ^ (row & 7)) << 4)); \
+    }                                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                   \
+      const int row = wn * WN + j * 16 + lrow;                                                         \
+      bf[j] = *reinterpret_cast<const gran_t*>(sB + (buf_) * B_BYTES + row * 128 + ((kg ^ (row & 7)) << 4)); \
+    }                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                     \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                 \
+        if constexpr (ABLATE & 2) { asm volatile("" ::"v"(af[i]), "v"(bf[j])); }                       \
+        else acc[i][j] = mma_granule<T>(af[i], bf[j], acc[i][j]);                                      \
+      }                                                                                                \
+  }
+
   f32x4_t acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -238,28 +264,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
     if (kt + 1 < nk && !(ABLATE & 1)) {
       if constexpr (UNIK) { CFT_LOAD_TILE_U(buf ^ 1) } else { CFT_LOAD_TILE(kt + 1, buf ^ 1) }
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kg = ks * 4 + lgrp;
-      gran_t af[MT], bf[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = wm * WM + i * 16 + lrow;
-        af[i] = *reinterpret_cast<const gran_t*>(sA + buf * A_BYTES + row * 128 + ((kg ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int row = wn * WN + j * 16 + lrow;
-        bf[j] = *reinterpret_cast<const gran_t*>(sB + buf * B_BYTES + row * 128 + ((kg ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          if constexpr (ABLATE & 2) { asm volatile("" ::"v"(af[i]), "v"(bf[j])); }
-          else acc[i][j] = mma_granule<T>(af[i], bf[j], acc[i][j]);
-        }
-    }
+    CFT_COMPUTE_STEP(buf)
     if (kt + 1 < nk) CFT_STORE_TILE(buf ^ 1)
     __syncthreads();
   }
@@ -267,6 +272,57 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
 #undef CFT_LOAD_TILE_U
 #undef CFT_STORE_TILE
 
+  if constexpr (CHAIN) {
+    static_assert(GLDS && sizeof(T) == 2 && BN % RPP == 0, "chained GEMM: 16-bit operands, LDS-DMA staging");
+    typedef typename Half16<T>::type TH;
+    // (every wave is past the barrier that ended the last K step: both staging buffers are free)
+    const int nk2 = p.N >> 6;                      // K steps of the second GEMM = 64-channel images of this tile (host: N % 64 == 0, <= 2)
+#pragma unroll 1
+    for (int k2 = 0; k2 < nk2; ++k2)               // second layer's weights [N2][N] -> the B buffers, the staging pattern of the K loop
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        const int n = r0 + i * RPP;
+        const unsigned char* src = (n < p.N2) ? p.w2 + ((long)n * p.N + k2 * 64 + g * GE) * ES : zero_page;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sB + k2 * B_BYTES + i * (RPP * 128) + wave * 1024), 16, 0, 0);
+      }
+    float bias2_v[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = wn * WN + j * 16 + lrow;
+      bias2_v[j] = (p.bias2 != nullptr && n < p.N2) ? p.bias2[n] : 0.0f;
+    }
+    // First layer's bias + SiLU + rounding on the accumulators; lanes l / l^1 hold neighbouring channels of the same four pixels:
+    // they swap half of their values (one DPP move) so that each writes two packed channel PAIRS (even lane: pixels 0,1; odd: 2,3).
+    const bool odd = lane & 1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act<CFT_ACT_SILU>(acc[i][j][e] + bias_v[j]);
+        const uint32_t r01 = Elem<TH>::pack2(v[0], v[1]), r23 = Elem<TH>::pack2(v[2], v[3]);
+        const uint32_t got = (uint32_t)__builtin_amdgcn_mov_dpp((int)(odd ? r01 : r23), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        const uint32_t d0 = odd ? ((got & 0xffffu) | (r23 << 16)) : ((r01 & 0xffffu) | (got << 16));
+        const uint32_t d1 = odd ? ((got >> 16) | (r23 & 0xffff0000u)) : ((r01 >> 16) | (got & 0xffff0000u));
+        const int row = wm * WM + i * 16 + lgrp * 4 + (odd ? 2 : 0);
+        const int col = wn * WN + j * 16 + (lrow & 14);
+        const int c = col & 63;
+        unsigned char* img = sA + (col >> 6) * A_BYTES + (c & 7) * 2;
+        *reinterpret_cast<uint32_t*>(img + row * 128 + (((c >> 3) ^ (row & 7)) << 4)) = d0;
+        *reinterpret_cast<uint32_t*>(img + (row + 1) * 128 + (((c >> 3) ^ ((row + 1) & 7)) << 4)) = d1;
+        acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    __syncthreads();
+#pragma unroll 1
+    for (int k2 = 0; k2 < nk2; ++k2) { CFT_COMPUTE_STEP(k2) }
+    __syncthreads();
+    ConvParams p2 = p;
+    p2.N = p.N2;
+    p2.res = nullptr;
+    conv_epilogue<TH, WM, WN>(p2, acc, smem, m0, 0, wm, wn, wave, lane, bias2_v);
+    return;
+  }
   if constexpr (ABLATE & 16) {   // timing probe: no epilogue (keep the accumulators alive)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -299,14 +355,14 @@ extern "C" int cft_set_conv_variant(int v) {
   return old;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0, bool UNIK = false>
+template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0, bool UNIK = false, bool CHAIN = false>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
   constexpr int smem_bytes = 2 * (BM + BN) * 128;
-  cft_allow_lds<&conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE, UNIK>>(smem_bytes);
+  cft_allow_lds<&conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE, UNIK, CHAIN>>(smem_bytes);
   ConvParams q = p;
   const int tilesM = (p.M + BM - 1) / BM;
   q.tilesN = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE, UNIK>), dim3(tilesM * q.tilesN), dim3(64 * WGM * WGN), smem_bytes, stream, q);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE, UNIK, CHAIN>), dim3(tilesM * q.tilesN), dim3(64 * WGM * WGN), smem_bytes, stream, q);
   return cft_check_launch("conv_gemm_kernel");
 }
 
@@ -418,11 +474,10 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   return launch_auto<T, 64, 128, 2, 4>(p, stream);
 }
 
-extern "C" int cft_conv2d(const void* x, const void* w, const float* bias, const void* res, void* y,
-                          int B, int H, int W, int cin, int ldx, int xoff,
-                          int n, int kpad, int ksize, int stride,
-                          int ldy, int yoff, int ldr, int roff,
-                          int act, int dtype, int out_dtype, int res_dtype, void* stream) {
+// Validate one conv layer's geometry and fill the launch parameters (shared by cft_conv2d and cft_conv2d_chain).
+static int fill_conv_params(ConvParams& p, const void* x, const void* w, const float* bias, const void* res, void* y,
+                            int B, int H, int W, int cin, int ldx, int xoff, int n, int kpad, int ksize, int stride,
+                            int ldy, int yoff, int ldr, int roff, int act, int dtype, int out_dtype, int res_dtype) {
   CFT_REQUIRE(x && w && y, "cft_conv2d: null pointer");
   CFT_REQUIRE(cft_is_dtype(dtype), "cft_conv2d: dtype must be CFT_BF16, CFT_F16 or CFT_F32");
   CFT_REQUIRE(out_dtype == dtype || out_dtype == CFT_F32, "cft_conv2d: out_dtype must be the compute dtype or CFT_F32");
@@ -439,7 +494,6 @@ extern "C" int cft_conv2d(const void* x, const void* w, const float* bias, const
   const long M = (long)B * Ho * Wo;
   CFT_REQUIRE(M < (1L << 31) && (long)B * H * W * ldx < (1L << 31) && M * ldy < (1L << 31),
               "cft_conv2d: tensor exceeds 2^31 elements (split the batch)");
-  ConvParams p;
   p.x = (const unsigned char*)x; p.w = (const unsigned char*)w; p.bias = bias;
   p.res = (const unsigned char*)res; p.y = (unsigned char*)y;
   p.H = H; p.W = W; p.Cin = cin; p.ldx = ldx; p.xoff = xoff;
@@ -448,10 +502,63 @@ extern "C" int cft_conv2d(const void* x, const void* w, const float* bias, const
   p.KS = ksize; p.stride = stride; p.pad = pad;
   p.act = act; p.out_f32 = out_dtype == CFT_F32; p.res_f32 = res_dtype == CFT_F32;
   p.M = (int)M; p.tilesN = 0;
+  p.w2 = nullptr; p.bias2 = nullptr; p.N2 = 0;
   p.x_bytes = (long)B * H * W * ldx * cft_elem_size(dtype);
   p.w_bytes = (long)n * kpad * cft_elem_size(dtype);
   set_magic(Wo, p.wo_mul, p.wo_sh);
   set_magic(Ho, p.ho_mul, p.ho_sh);
+  return CFT_OK;
+}
+
+extern "C" int cft_conv2d(const void* x, const void* w, const float* bias, const void* res, void* y,
+                          int B, int H, int W, int cin, int ldx, int xoff,
+                          int n, int kpad, int ksize, int stride,
+                          int ldy, int yoff, int ldr, int roff,
+                          int act, int dtype, int out_dtype, int res_dtype, void* stream) {
+  ConvParams p;
+  const int rc = fill_conv_params(p, x, w, bias, res, y, B, H, W, cin, ldx, xoff, n, kpad, ksize, stride,
+                                  ldy, yoff, ldr, roff, act, dtype, out_dtype, res_dtype);
+  if (rc != CFT_OK) return rc;
   CFT_DISPATCH_DTYPE(dtype, T, return dispatch_conv<T>(p, as_stream(stream)));
   return CFT_EINVAL;
+}
+
+// Which layer pairs the chained kernel takes (cft_conv2d_chain / cft_conv2d_chain_ok): 16-bit operands, a first layer on the
+// uniform K walk whose whole width is one 128-wide tile of exactly two 64-channel images, SiLU, and a pointwise second layer
+// of at most 128 outputs - in the CFT networks the stride-2 Conv (64 -> 128) in front of the first C3 of each stream.
+static bool chain_ok(const ConvParams& p, int n2, int dtype) {
+  return (dtype == CFT_BF16 || dtype == CFT_F16) && p.N == 128 && n2 >= 8 && n2 <= 128 && n2 % 8 == 0 && p.Cin % 64 == 0 && p.Kpad == p.K &&
+         2L * p.Kpad * 2 + 128 <= CFT_ZERO_REGION_BYTES;
+}
+
+template <typename T>
+static int dispatch_chain(const ConvParams& p, hipStream_t stream) {
+  if constexpr (sizeof(T) == 2) return launch_conv<T, 192, 128, 2, 4, true, 0, true, true>(p, stream);
+  else return CFT_EINVAL;
+}
+
+extern "C" int cft_conv2d_chain(const void* x, const void* w1, const float* bias1, const void* w2, const float* bias2, void* y,
+                                int B, int H, int W, int cin, int ldx, int xoff,
+                                int n1, int kpad1, int ksize, int stride, int n2,
+                                int ldy, int yoff, int act2, int dtype, void* stream) {
+  CFT_REQUIRE(w2 != nullptr, "cft_conv2d_chain: null pointer");
+  ConvParams p;
+  const int rc = fill_conv_params(p, x, w1, bias1, nullptr, y, B, H, W, cin, ldx, xoff, n1, kpad1, ksize, stride,
+                                  ldy, yoff, 0, 0, act2, dtype, dtype, dtype);
+  if (rc != CFT_OK) return rc;
+  CFT_REQUIRE(n2 % 8 == 0 && n2 > 0, "cft_conv2d_chain: n2 must be a positive multiple of 8");
+  CFT_REQUIRE(chain_ok(p, n2, dtype), "cft_conv2d_chain: layer pair not eligible (ask cft_conv2d_chain_ok; run the two layers with cft_conv2d)");
+  p.w2 = (const unsigned char*)w2; p.bias2 = bias2; p.N2 = n2;
+  CFT_DISPATCH_DTYPE(dtype, T, return dispatch_chain<T>(p, as_stream(stream)));
+  return CFT_EINVAL;
+}
+
+// 1 if cft_conv2d_chain takes this pair of layers (first layer: its cft_conv2d geometry, SiLU; second: pointwise, n2 outputs), else 0.
+extern "C" int cft_conv2d_chain_ok(int B, int H, int W, int cin, int n1, int kpad1, int ksize, int stride, int n2, int dtype) {
+  if (!(B > 0 && H > 0 && W > 0 && cin > 0 && n1 > 0 && (ksize == 1 || ksize == 3 || ksize == 5) && stride >= 1 && cft_is_dtype(dtype))) return 0;
+  const int pad = ksize / 2;
+  const long Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+  ConvParams p;
+  p.M = (int)((long)B * Ho * Wo); p.N = n1; p.Cin = cin; p.Kpad = kpad1; p.K = ksize * ksize * cin;
+  return (long)B * Ho * Wo < (1L << 31) && chain_ok(p, n2, dtype) ? 1 : 0;
 }

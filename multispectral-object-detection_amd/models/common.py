@@ -82,6 +82,23 @@ class PendingUpsample(_Pending):
         return torch.Size((B, C, H << self.up, W << self.up))
 
 
+class PendingConv(_Pending):
+    """Output of a ``Conv`` whose only consumer is the ``C3`` behind it (``Model.chain_plan``): that C3 runs the conv and its own
+    packed cv1|cv2 as ONE kernel (``ops.conv2d_chain``) when the pair is eligible, and the conv's output tensor never exists."""
+
+    def __init__(self, conv, x):
+        self.conv, self.x = conv, x
+
+    def materialize(self):
+        return self.conv(self.x)
+
+    @property
+    def shape(self):
+        B, _, H, W = self.x.shape
+        k, s = self.conv.conv.kernel_size[0], self.conv.conv.stride[0]
+        return torch.Size((B, self.conv.conv.out_channels, (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1))
+
+
 def resolve(x):
     return x.materialize() if isinstance(x, _Pending) else x
 
@@ -227,16 +244,25 @@ class C3(_Packed):
         return ops.pack_conv(torch.cat([w1, w2], 0), torch.cat([b1, b2], 0), dtype, device=device)
 
     def forward(self, x, out=None):
-        x = resolve(x)
         c_ = self.cv1.conv.out_channels
         if _act_code(self.cv1.act) != _act_code(self.cv2.act):
             raise NotImplementedError("C3.cv1 and C3.cv2 must share an activation")
-        if self.training:      # batch statistics are per BatchNorm: cv1 and cv2 run separately into the concat buffer
+        cat = None
+        if isinstance(x, PendingConv) and not self.training:      # the Conv in front of this C3 was left to it: one kernel for both
+            src, conv = resolve(x.x), x.conv
+            pk1 = conv._packed(src.dtype, src.device)
+            if _act_code(conv.act) == ACT_SILU and ops.conv2d_chain_ok(src, pk1, self._packed(src.dtype, src.device)):
+                cat = ops.conv2d_chain(src, pk1, self._packed(src.dtype, src.device), _act_code(self.cv1.act))
+        if cat is not None:
+            pass
+        elif self.training:      # batch statistics are per BatchNorm: cv1 and cv2 run separately into the concat buffer
+            x = resolve(x)
             B, _, H, W = x.shape
             cat = ops.new_nhwc(B, H, W, 2 * c_, x.dtype, x.device)
             self.cv1(x, out=cat[:, :c_])
             self.cv2(x, out=cat[:, c_:])
         else:
+            x = resolve(x)
             cat = ops.conv2d(x, self._packed(x.dtype, x.device), _act_code(self.cv1.act))     # [B, 2c_, H, W]
         head = cat[:, :c_]
         y = head

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .common import (GPT, NMS, SPP, Add, Add2, Bottleneck, C3, Concat, Conv, Focus, PendingBilinear, Upsample, _Packed, autoShape, resolve,
+from .common import (GPT, NMS, SPP, Add, Add2, Bottleneck, C3, Concat, Conv, Focus, PendingBilinear, PendingConv, Upsample, _Packed, autoShape, resolve,
                      ACT_NONE, invalidate_packed)
 
 logger = logging.getLogger(__name__)
@@ -333,6 +333,27 @@ class Model(nn.Module):
         return plan
 
     # ---- CFT output fusion: both Add2 layers behind a GPT block and the Add that sums them run as ONE kernel ----------------
+    def chain_plan(self):
+        """Indices of the ``Conv`` layers whose output is read by exactly one layer, the ``C3`` right behind them (``f == -1``): yaml
+        rows 1, 3, 6, 8, 13, 15 of the x3 configs (the convs in front of SPP or Concat do not qualify).  Such a conv is handed to its
+        C3 un-run (``PendingConv``); the C3 issues both as one kernel when ``ops.conv2d_chain_ok`` accepts the pair (64 -> 128
+        channels: rows 1 and 6 of yolov5l), else it runs the conv itself.  Readers are counted from the ``f`` fields, not from
+        ``self.save``: the reference's ``x % i`` book-keeping (models/yolo_test.py:349) files the IR Focus's ``f = -4`` as a reader of
+        row 1, which nothing reads."""
+        plan = self.__dict__.get("_chain_plan")
+        if plan is None:
+            layers = list(self.model)
+            readers = {}
+            for j, m in enumerate(layers):
+                if m.f == -4 or j == 0:
+                    continue
+                for f in ([m.f] if isinstance(m.f, int) else m.f):
+                    readers.setdefault(j - 1 if f == -1 else f % j, set()).add(j)
+            plan = self.__dict__["_chain_plan"] = frozenset(
+                i for i, m in enumerate(layers[:-1])
+                if type(m) is Conv and type(layers[i + 1]) is C3 and layers[i + 1].f == -1 and readers.get(i) == {i + 1})
+        return plan
+
     def cft_fusion_plan(self):
         """{index of the first Add2 behind a GPT block: (GPT index, index of the second Add2, index of the Add that consumes both
         or None)} - yaml rows 10-12 + 29 (17-19 + 30, 26-28 + 31) of the x3 configs.  The pattern is matched structurally; a config
@@ -402,9 +423,11 @@ class Model(nn.Module):
         tgt = self.concat_plan().get(m.i) if cbufs is not None else None
         if tgt is not None:
             cidx, off, c, total = tgt
-            t = resolve(x[0] if isinstance(x, (list, tuple)) else x)
+            t = x[0] if isinstance(x, (list, tuple)) else x
+            shape = t.shape if isinstance(t, PendingConv) else None     # (stays un-run: only its geometry is needed here)
+            t = t.x if isinstance(t, PendingConv) else resolve(t)
             if isinstance(t, torch.Tensor) and t.is_cuda and t.dim() == 4:
-                B, _, H, W = t.shape
+                B, _, H, W = shape or t.shape
                 if type(m) is Conv:
                     k, s_ = m.conv.kernel_size[0], m.conv.stride[0]
                     H, W = (H + 2 * (k // 2) - k) // s_ + 1, (W + 2 * (k // 2) - k) // s_ + 1
@@ -415,6 +438,9 @@ class Model(nn.Module):
                     return m(x, out=buf[:, off:off + c])
         if cbufs is not None and isinstance(m, Concat) and m.i in cbufs:
             return m(x, out=cbufs[m.i])
+        if (cbufs is not None and not self.training and m.i in self.chain_plan() and self.__dict__.get("chain_convs", True)
+                and isinstance(x, torch.Tensor) and x.dtype in (torch.bfloat16, torch.float16)):
+            return PendingConv(m, x)                 # left to the C3 behind it (one kernel for the conv and the C3's cv1|cv2)
         return m(x)
 
     def forward_once(self, x, x2, profile=False, until_detect=False):
@@ -531,6 +557,7 @@ class Model(nn.Module):
             self.model = self.model[:-1]
         self.__dict__.pop("_concat_plan", None)
         self.__dict__.pop("_cft_plan", None)
+        self.__dict__.pop("_chain_plan", None)
         self._graphs.clear()
         return self
 

@@ -205,6 +205,45 @@ def conv2d(x, pk, act, residual=None, out=None, out_dtype=None):
     return out
 
 
+def conv2d_chain_ok(x, pk1, pk2):
+    """True when ``conv2d_chain`` takes this pair: conv ``pk1`` (SiLU) then the pointwise conv ``pk2`` on its output (cft_conv2d_chain_ok)."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16)):
+        return False
+    if pk2.k != 1 or pk2.s != 1 or pk2.cin != pk1.n or pk2.kpad != pk1.n or pk1.n_valid != pk1.n or x.shape[1] != pk1.cin:
+        return False
+    B, _, H, W = x.shape
+    return bool(_lib.load().cft_conv2d_chain_ok(B, H, W, pk1.cin, pk1.n, pk1.kpad, pk1.k, pk1.s, pk2.n, _dt(x.dtype)))
+
+
+def conv2d_chain(x, pk1, pk2, act2, out=None):
+    """act2(conv1x1(SiLU(conv(x)))) as ONE kernel (cft_conv2d_chain): the first conv's output tile becomes the second GEMM's A operand
+    in LDS.  Bit-identical to ``conv2d(conv2d(x, pk1, ACT_SILU), pk2, act2)``."""
+    _require_cuda(x, "conv2d_chain")
+    if not conv2d_chain_ok(x, pk1, pk2):
+        raise ValueError("conv2d_chain: layer pair not eligible (conv2d_chain_ok)")
+    x, ldx = as_nhwc(x)
+    B, C, H, W = x.shape
+    p = pk1.k // 2
+    Ho, Wo = (H + 2 * p - pk1.k) // pk1.s + 1, (W + 2 * p - pk1.k) // pk1.s + 1
+    if out is None:
+        out = new_nhwc(B, Ho, Wo, pk2.n, x.dtype, x.device)
+    if tuple(out.shape) != (B, pk2.n, Ho, Wo) or out.dtype != x.dtype:
+        raise ValueError(f"conv2d_chain: out has shape {tuple(out.shape)}, expected {(B, pk2.n, Ho, Wo)}")
+    ldy = _view_ld(out, "conv2d_chain out")
+    lib = _lib.load()
+    es = x.element_size()
+    M = B * Ho * Wo
+    abytes = B * H * W * pk1.cin * es + M * pk2.n_valid * es + (pk1.w.numel() + pk2.w.numel()) * es
+    args = (x.data_ptr(), pk1.w.data_ptr(), pk1.bias.data_ptr() if pk1.bias is not None else None,
+            pk2.w.data_ptr(), pk2.bias.data_ptr() if pk2.bias is not None else None, out.data_ptr(),
+            B, H, W, pk1.cin, ldx, 0, pk1.n, pk1.kpad, pk1.k, pk1.s, pk2.n, ldy, 0, act2, _dt(x.dtype), _stream())
+    # counted with the GEMM family: both layers' FLOPs, one launch
+    st = _timed(f"conv_chain_k{pk1.k}s{pk1.s}_n{pk1.n}_K{pk1.kpad}+{pk2.kpad}", M * (pk1.flops_per_row + pk2.flops_per_row), abytes,
+                lambda: lib.cft_conv2d_chain(*args))
+    _lib.check(st, "cft_conv2d_chain")
+    return out
+
+
 # cft_bottleneck covers 64 and 128 channels (activation patch resident in LDS, weights streamed through a 4-slot LDS ring, two
 # workgroups per CU: 147-173 vs 220-234 us for the two launches it replaces at 128 channels - profiles/r02_bottleneck128.md).
 FUSED_BOTTLENECK_WIDTHS = (64, 128)

@@ -421,6 +421,39 @@ def test_cft_output_fusion_matches_the_three_launch_path(dev, dtype):
         assert _sig_err([r.cpu() for r in raw_f], [r.cpu() for r in raw_u]) < 2e-2 and e_f <= 1.15 * e_u + 1e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_conv_c3_chain_is_bit_identical_to_the_layerwise_walk(dev, dtype):
+    """Model.chain_plan: the stride-2 Conv in front of every backbone C3 is handed to that C3 un-run; where the pair is eligible
+    (yolov5l: rows 1-2 and 6-7, 64 -> 128 channels) both run as one cft_conv2d_chain kernel.  Same arithmetic: the detections are
+    bit-identical to the walk that runs every layer on its own, on one lane or two, and under HIP-graph replay."""
+    from msod_amd import ops
+    from msod_amd.utils.seeded import seeded_inputs
+    cfg, model, sd = _seeded("cfg3", 3)
+    model = model.to(dev).set_compute_dtype(dtype)
+    assert model.chain_plan() == frozenset({1, 3, 6, 8, 13, 15})
+    rgb, ir = seeded_inputs(2, 192, 256, 3)
+    x, x2 = rgb.to(dev), ir.to(dev)
+    log = []
+    with torch.no_grad():
+        ops.set_launch_log(log)
+        try:
+            model.overlap_streams = False
+            pred_c, raw_c = model.forward_once(x, x2)
+        finally:
+            ops.set_launch_log(None)
+        model.overlap_streams = True
+        pred_c2, _ = model.forward_once(x, x2)
+        model.chain_convs = False
+        pred_u, raw_u = model.forward_once(x, x2)
+        model.chain_convs = True
+        model.capture(2, 192, 256)
+        pred_g = model(x, x2)[0].clone()
+    torch.cuda.synchronize()
+    assert sum(1 for rec in log if rec[0].startswith("conv_chain_")) == 2          # one per stream
+    assert torch.equal(pred_c, pred_u) and torch.equal(pred_c2, pred_u) and torch.equal(pred_g, pred_u)
+    assert all(torch.equal(a, b) for a, b in zip(raw_c, raw_u))
+
+
 def test_captured_graph_is_dropped_when_weights_change(dev):
     """a captured graph replays the packed weights of capture time; in-place weight updates,
     load_state_dict and .to()/.half() must not return detections of the old weights."""

@@ -222,6 +222,35 @@ def test_gpt_upsample_add_dual(dev, dtype, hw, C):
     assert rel_err(to_cpu_f32(osum), exact) < tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("B,H,W,cin,k,s,n2", [(2, 160, 160, 64, 3, 2, 128), (1, 51, 37, 64, 3, 2, 128), (3, 40, 24, 128, 3, 1, 64),
+                                              (2, 33, 20, 64, 1, 1, 72), (1, 9, 9, 192, 3, 2, 128)])
+def test_conv2d_chain_is_bit_identical_to_two_launches(dev, dtype, B, H, W, cin, k, s, n2):
+    """cft_conv2d_chain (stride-2 Conv + the C3's packed cv1|cv2 in one kernel; the 128-channel tensor between them stays in LDS):
+    same values, roundings and k order as the two cft_conv2d launches -> bit-identical, for full tiles, pixel tails (M % 192 != 0),
+    n2 < 128 and other first-layer geometries; a channel-slice destination works; ineligible pairs are refused."""
+    from msod_amd import ops
+    x = to_dev_nhwc(_q(_rnd(B, cin, H, W, seed=31), dtype), dev, dtype)
+    pk1 = ops.pack_conv(_rnd(128, cin, k, k, seed=32) * (2.0 / (cin * k * k)) ** 0.5, _rnd(128, seed=33) * 0.1, dtype, s=s, device=dev)
+    pk2 = ops.pack_conv(_rnd(n2, 128, 1, 1, seed=34) * (2.0 / 128) ** 0.5, _rnd(n2, seed=35) * 0.1, dtype, device=dev)
+    assert ops.conv2d_chain_ok(x, pk1, pk2)
+    two = ops.conv2d(ops.conv2d(x, pk1, ops.ACT_SILU), pk2, ops.ACT_SILU)
+    one = ops.conv2d_chain(x, pk1, pk2, ops.ACT_SILU)
+    Ho, Wo = two.shape[2], two.shape[3]
+    buf = ops.new_nhwc(B, Ho, Wo, pk2.n + 16, dtype, dev)
+    buf.zero_()
+    sl = ops.conv2d_chain(x, pk1, pk2, ops.ACT_NONE, out=buf[:, 8:8 + pk2.n])
+    lin = ops.conv2d(ops.conv2d(x, pk1, ops.ACT_SILU), pk2, ops.ACT_NONE)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two) and float(two.float().abs().max()) > 0.1
+    assert torch.equal(sl, lin) and float(buf[:, :8].float().abs().max()) == 0.0 and float(buf[:, 8 + pk2.n:].float().abs().max()) == 0.0
+    pk_bad = ops.pack_conv(_rnd(64, cin, k, k, seed=36), None, dtype, s=s, device=dev)          # first layer not 128 wide
+    pk2_bad = ops.pack_conv(_rnd(n2, 64, 1, 1, seed=37), None, dtype, device=dev)
+    assert not ops.conv2d_chain_ok(x, pk_bad, pk2_bad)
+    with pytest.raises(ValueError):
+        ops.conv2d_chain(x, pk_bad, pk2_bad, ops.ACT_SILU)
+
+
 @pytest.mark.parametrize("C", [64, 256, 320, 1024, 1280])
 def test_layernorm(dev, C):
     from msod_amd import ops

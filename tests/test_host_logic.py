@@ -319,6 +319,10 @@ def test_cft_fusion_plan_and_nms_module_structure():
     m = Model(named_config("cfg3"))
     assert m.cft_fusion_plan() == {11: (10, 12, 29), 18: (17, 19, 30), 27: (26, 28, 31)}
     assert Model(named_config("cfg1")).cft_fusion_plan() == {}
+    # the Conv layers handed un-run to the C3 behind them (yaml rows 1-2, 3-4, 13-14 of the RGB stream, 6-7, 8-9, 15-16 of the IR
+    # stream); rows 20 / 23 feed SPP and the head's stride-2 convs feed Concat: not in the plan
+    chain = m.chain_plan()
+    assert chain == frozenset({1, 3, 6, 8, 13, 15}) and 1 in m.save      # (row 1 is "saved" by the reference's f = -4 book-keeping only)
     n = len(m.model)
     m.nms()
     assert len(m.model) == n + 1 and type(m.model[-1]) is NMS and m.model[-1].f == -1 and m.model[-1].i == n

@@ -1,0 +1,67 @@
+"""Per-pair timing of cft_conv2d_chain against the two cft_conv2d launches it replaces (stride-2 Conv 64 -> 128 + the C3's packed
+cv1|cv2 128 -> 128 at the bench shape), interleaved and warmed; HIP events on the launch stream.
+  python tools/chain_bench.py [--batch 64] [--size 640]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import msod_amd  # noqa: E402,F401
+from msod_amd import ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    for dtype in (torch.bfloat16, torch.float16):
+        H = args.size // 2
+        x = ops.new_nhwc(args.batch, H, H, 64, dtype, dev)
+        x.copy_(torch.randn(args.batch, 64, H, H, generator=g).to(dtype))
+        pk1 = ops.pack_conv(torch.randn(128, 64, 3, 3, generator=g) * 0.06, torch.randn(128, generator=g) * 0.1, dtype, s=2, device=dev)
+        pk2 = ops.pack_conv(torch.randn(128, 128, 1, 1, generator=g) * 0.12, torch.randn(128, generator=g) * 0.1, dtype, device=dev)
+        mid = ops.conv2d(x, pk1, ops.ACT_SILU)
+        out2 = ops.conv2d(mid, pk2, ops.ACT_SILU)
+        out1 = ops.conv2d_chain(x, pk1, pk2, ops.ACT_SILU)
+        torch.cuda.synchronize()
+        assert torch.equal(out1, out2)
+
+        def two():
+            ops.conv2d(x, pk1, ops.ACT_SILU, out=mid)
+            ops.conv2d(mid, pk2, ops.ACT_SILU, out=out2)
+
+        def first():
+            ops.conv2d(x, pk1, ops.ACT_SILU, out=mid)
+
+        def one():
+            ops.conv2d_chain(x, pk1, pk2, ops.ACT_SILU, out=out1)
+
+        best = {}
+        for rnd in range(4):
+            for name, fn in (("two launches", two), ("first layer alone", first), ("chained", one)):
+                fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / args.iters
+                if rnd > 0:
+                    best[name] = min(best.get(name, 1e9), us)
+        M = args.batch * (H // 2) ** 2
+        fl = 2.0 * M * (128 * 576 + 128 * 128)
+        print(f"{str(dtype):16s} {args.batch} x 64ch {H}x{H} -> 128 -> 128 @ {H // 2}:  " +
+              "   ".join(f"{k} {v:7.1f} us" for k, v in best.items()) +
+              f"   chained = {best['chained'] / best['two launches']:.3f} x two launches, {fl / best['chained'] / 1e6:.0f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()

@@ -146,6 +146,17 @@ PY
     timeout 2400 python -m pytest tests -q -m gpu -x > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -5 $O/tests.log
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/summary.txt; tail -3 $O/smoke.log
     timeout 900 python bench.py > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee -a $O/summary.txt; tail -2 $O/bench.log; head -c 3000 $O/bench.json ;;
+  r4e)         # round 4: Conv + C3.cv1|cv2 chained kernel: bit-identity tests, per-pair timing, whole-forward A/B (interleaved)
+    timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -q -m gpu -x -k "chain" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -5 $O/tests.log
+    timeout 300 python tools/chain_bench.py > $O/chain_pairs.txt 2>&1; cat $O/chain_pairs.txt
+    X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
+    run() { tag=$1; shift; timeout 300 python bench.py $X "$@" > $O/b.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/b.json'));print('$tag', d['value'], d['ms_per_step'], (d.get('single_in_flight') or {}).get('value'), d['roofline']['whole_step']['frac'], d['config'].get('stream_group_probe_ms_per_step'))" | tee -a $O/summary.txt; }
+    run "chained Conv+C3 (default)"
+    run "two launches (--no-conv-chain)" --no-conv-chain
+    run "chained Conv+C3 (default)"
+    run "two launches (--no-conv-chain)" --no-conv-chain
+    run "bs8 in-flight 4 chained" --batch 8 --in-flight 4
+    run "bs8 in-flight 4 two launches" --batch 8 --in-flight 4 --no-conv-chain ;;
   pmc4)        # round 4: PMC counters of the shipped 16-wave kernel (27) and the probe build's 8-wave kernel (91) on 3x3 256->256 @40 (+res)
     for v in 27 91; do
       bash tools/pmc.sh $O/v$v -- python tools/gemm_bench.py --lib multispectral-object-detection_amd/libcft_hip_probes.so --variants $v --iters 10 --rounds 1 --only "bneck 3x3 256->256" --out $JOB/g$v.json > $O/pmc_v$v.log 2>&1
