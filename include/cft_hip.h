@@ -72,8 +72,9 @@ int cft_conv2d(const void* x, const void* w, const float* bias, const void* res,
  * packed as one [n2][n1] weight).  y = act2(conv1x1(SiLU(conv(x)))):  the first layer's output tile is rounded to dtype in LDS and
  * becomes the second GEMM's A operand, so the n1-channel tensor between the layers is never written or read.  Results are
  * bit-identical to the two cft_conv2d launches.  x / w1 / bias1 / geometry as cft_conv2d; w2: dtype [n2][n1] (k = 1), bias2
- * float[n2] or NULL; y: dtype, ldy / yoff.  Eligible pairs only (cft_conv2d_chain_ok returns 1): bf16 / fp16, n1 == 128,
- * cin % 64 == 0, kpad1 == k*k*cin, n2 <= 128; anything else is CFT_EINVAL.
+ * float[n2] or NULL; y: dtype, ldy / yoff.  Eligible pairs only (cft_conv2d_chain_ok returns 1): bf16 / fp16, n1 == 128 (192 x 128
+ * tile, two workgroups per CU, second layer's weights resident in LDS) or n1 == 256 (256 x 256 tile, 160 KiB of LDS, second
+ * layer's weights streamed a K step at a time), cin % 64 == 0, kpad1 == k*k*cin, n2 <= n1; anything else is CFT_EINVAL.
  */
 int cft_conv2d_chain(const void* x, const void* w1, const float* bias1, const void* w2, const float* bias2, void* y,
                      int B, int H, int W, int cin, int ldx, int xoff,

@@ -227,17 +227,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
   int u_ci = 0;                                  // scalar: channel offset of the K step inside its tap (tap-major walk)
 
 // The two 32-wide k sub-steps of one staged K step: fragment reads + MFMAs of LDS buffer buf_.
-#define CFT_COMPUTE_STEP(buf_)                                                                         \
+#define CFT_COMPUTE_STEP(buf_) CFT_COMPUTE_STEP_AT(sA + (buf_) * A_BYTES, sB + (buf_) * B_BYTES)
+#define CFT_COMPUTE_STEP_AT(abase_, bbase_)                                                            \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                   \
     const int kg = ks * 4 + lgrp;                                                                      \
     gran_t af[MT], bf[NT];                                                                             \
     _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                   \
       const int row = wm * WM + i * 16 + lrow;                                                         \
-      af[i] = *reinterpret_cast<const gran_t*>(sA + (buf_) * A_BYTES + row * 128 + ((kg ^ (row & 7)) << 4)); \
+      af[i] = *reinterpret_cast<const gran_t*>((abase_) + row * 128 + ((kg ^ (row & 7)) << 4));         \
     }                                                                                                  \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                   \
       const int row = wn * WN + j * 16 + lrow;                                                         \
-      bf[j] = *reinterpret_cast<const gran_t*>(sB + (buf_) * B_BYTES + row * 128 + ((kg ^ (row & 7)) << 4)); \
+      bf[j] = *reinterpret_cast<const gran_t*>((bbase_) + row * 128 + ((kg ^ (row & 7)) << 4));         \
     }                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                     \
       _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                 \
@@ -274,17 +275,27 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
 
   if constexpr (CHAIN) {
     static_assert(GLDS && sizeof(T) == 2 && BN % RPP == 0, "chained GEMM: 16-bit operands, LDS-DMA staging");
+    static_assert(BN % 64 == 0, "chained GEMM: the tile is cut into 64-channel images");
     typedef typename Half16<T>::type TH;
     // (every wave is past the barrier that ended the last K step: both staging buffers are free)
-    const int nk2 = p.N >> 6;                      // K steps of the second GEMM = 64-channel images of this tile (host: N % 64 == 0, <= 2)
-#pragma unroll 1
-    for (int k2 = 0; k2 < nk2; ++k2)               // second layer's weights [N2][N] -> the B buffers, the staging pattern of the K loop
+    // K steps of the second GEMM = 64-channel images of this tile (host: N == BN).  Two images: they and the second layer's weights
+    // take the places of the staging buffers.  Four (256-wide tile): the images fill all of the staging area and the weights stream
+    // through ONE extra buffer behind it, a K step at a time (launch_conv sizes the allocation).
+    constexpr int NK2 = BN / 64;
+    constexpr bool W2_RESIDENT = NK2 <= 2;
+    unsigned char* sB2 = W2_RESIDENT ? sB : smem + NK2 * A_BYTES;
+#define CFT_LOAD_W2(k2_, dst_)   /* second layer's weights [N2][N], K step k2_ -> dst_: the staging pattern of the K loop */   \
+  _Pragma("unroll") for (int i = 0; i < B_PER; ++i) {                                                   \
+    const int n = r0 + i * RPP;                                                                        \
+    const unsigned char* src = (n < p.N2) ? p.w2 + ((long)n * p.N + (k2_) * 64 + g * GE) * ES : zero_page; \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)((dst_) + i * (RPP * 128) + wave * 1024), 16, 0, 0); \
+  }
+    if constexpr (W2_RESIDENT) {
 #pragma unroll
-      for (int i = 0; i < B_PER; ++i) {
-        const int n = r0 + i * RPP;
-        const unsigned char* src = (n < p.N2) ? p.w2 + ((long)n * p.N + k2 * 64 + g * GE) * ES : zero_page;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sB + k2 * B_BYTES + i * (RPP * 128) + wave * 1024), 16, 0, 0);
-      }
+      for (int k2 = 0; k2 < NK2; ++k2) CFT_LOAD_W2(k2, sB2 + k2 * B_BYTES)
+    } else {
+      CFT_LOAD_W2(0, sB2)
+    }
     float bias2_v[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -313,9 +324,22 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
         *reinterpret_cast<uint32_t*>(img + (row + 1) * 128 + (((c >> 3) ^ ((row + 1) & 7)) << 4)) = d1;
         acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
-    __syncthreads();
+    if constexpr (W2_RESIDENT) {
+      __syncthreads();
+#pragma unroll
+      for (int k2 = 0; k2 < NK2; ++k2) { CFT_COMPUTE_STEP_AT(sA + k2 * A_BYTES, sB2 + k2 * B_BYTES) }
+    } else {
 #pragma unroll 1
-    for (int k2 = 0; k2 < nk2; ++k2) { CFT_COMPUTE_STEP(k2) }
+      for (int k2 = 0; k2 < NK2; ++k2) {
+        __syncthreads();                                   // this K step's weights have landed (first pass: and the images are written)
+        CFT_COMPUTE_STEP_AT(sA + k2 * A_BYTES, sB2)
+        if (k2 + 1 < NK2) {
+          __syncthreads();                                 // every wave is done with the buffer
+          CFT_LOAD_W2(k2 + 1, sB2)
+        }
+      }
+    }
+#undef CFT_LOAD_W2
     __syncthreads();
     ConvParams p2 = p;
     p2.N = p.N2;
@@ -357,7 +381,9 @@ extern "C" int cft_set_conv_variant(int v) {
 
 template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0, bool UNIK = false, bool CHAIN = false>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
-  constexpr int smem_bytes = 2 * (BM + BN) * 128;
+  // (chained kernel with four 64-channel images: they take all of the staging area, the second layer's weights one buffer behind it)
+  constexpr int smem_bytes = (CHAIN && BN / 64 > 2) ? (BN / 64) * BM * 128 + BN * 128 : 2 * (BM + BN) * 128;
+  static_assert(!CHAIN || (BN / 64) * BM * 128 >= 2 * (BM + BN) * 128 || BN / 64 <= 2, "chained GEMM: LDS map");
   cft_allow_lds<&conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE, UNIK, CHAIN>>(smem_bytes);
   ConvParams q = p;
   const int tilesM = (p.M + BM - 1) / BM;
@@ -524,17 +550,20 @@ extern "C" int cft_conv2d(const void* x, const void* w, const float* bias, const
 }
 
 // Which layer pairs the chained kernel takes (cft_conv2d_chain / cft_conv2d_chain_ok): 16-bit operands, a first layer on the
-// uniform K walk whose whole width is one 128-wide tile of exactly two 64-channel images, SiLU, and a pointwise second layer
-// of at most 128 outputs - in the CFT networks the stride-2 Conv (64 -> 128) in front of the first C3 of each stream.
+// uniform K walk whose whole width is ONE tile (128 or 256 channels = two or four 64-channel images), SiLU, and a pointwise
+// second layer no wider than the first - in the CFT networks the stride-2 Convs 64 -> 128 and 128 -> 256 in front of the
+// first two C3s of each stream (the 256 -> 512 conv does not fit: 512 channels x 256 pixels x 2 B = 256 KiB).
 static bool chain_ok(const ConvParams& p, int n2, int dtype) {
-  return (dtype == CFT_BF16 || dtype == CFT_F16) && p.N == 128 && n2 >= 8 && n2 <= 128 && n2 % 8 == 0 && p.Cin % 64 == 0 && p.Kpad == p.K &&
+  return (dtype == CFT_BF16 || dtype == CFT_F16) && (p.N == 128 || p.N == 256) && n2 >= 8 && n2 <= p.N && n2 % 8 == 0 && p.Cin % 64 == 0 && p.Kpad == p.K &&
          2L * p.Kpad * 2 + 128 <= CFT_ZERO_REGION_BYTES;
 }
 
 template <typename T>
 static int dispatch_chain(const ConvParams& p, hipStream_t stream) {
-  if constexpr (sizeof(T) == 2) return launch_conv<T, 192, 128, 2, 4, true, 0, true, true>(p, stream);
-  else return CFT_EINVAL;
+  if constexpr (sizeof(T) == 2) {
+    if (p.N == 128) return launch_conv<T, 192, 128, 2, 4, true, 0, true, true>(p, stream);   // two workgroups per CU (80 KiB)
+    return launch_conv<T, 256, 256, 4, 4, true, 0, true, true>(p, stream);                   // 16 waves, all 160 KiB
+  } else return CFT_EINVAL;
 }
 
 extern "C" int cft_conv2d_chain(const void* x, const void* w1, const float* bias1, const void* w2, const float* bias2, void* y,

@@ -336,8 +336,8 @@ class Model(nn.Module):
     def chain_plan(self):
         """Indices of the ``Conv`` layers whose output is read by exactly one layer, the ``C3`` right behind them (``f == -1``): yaml
         rows 1, 3, 6, 8, 13, 15 of the x3 configs (the convs in front of SPP or Concat do not qualify).  Such a conv is handed to its
-        C3 un-run (``PendingConv``); the C3 issues both as one kernel when ``ops.conv2d_chain_ok`` accepts the pair (64 -> 128
-        channels: rows 1 and 6 of yolov5l), else it runs the conv itself.  Readers are counted from the ``f`` fields, not from
+        C3 un-run (``PendingConv``); the C3 issues both as one kernel when ``ops.conv2d_chain_ok`` accepts the pair (a conv of 128
+        or 256 output channels: rows 1, 3, 6, 8 of yolov5l), else it runs the conv itself.  Readers are counted from the ``f`` fields, not from
         ``self.save``: the reference's ``x % i`` book-keeping (models/yolo_test.py:349) files the IR Focus's ``f = -4`` as a reader of
         row 1, which nothing reads."""
         plan = self.__dict__.get("_chain_plan")

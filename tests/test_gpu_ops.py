@@ -223,16 +223,19 @@ def test_gpt_upsample_add_dual(dev, dtype, hw, C):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("B,H,W,cin,k,s,n2", [(2, 160, 160, 64, 3, 2, 128), (1, 51, 37, 64, 3, 2, 128), (3, 40, 24, 128, 3, 1, 64),
-                                              (2, 33, 20, 64, 1, 1, 72), (1, 9, 9, 192, 3, 2, 128)])
-def test_conv2d_chain_is_bit_identical_to_two_launches(dev, dtype, B, H, W, cin, k, s, n2):
-    """cft_conv2d_chain (stride-2 Conv + the C3's packed cv1|cv2 in one kernel; the 128-channel tensor between them stays in LDS):
-    same values, roundings and k order as the two cft_conv2d launches -> bit-identical, for full tiles, pixel tails (M % 192 != 0),
-    n2 < 128 and other first-layer geometries; a channel-slice destination works; ineligible pairs are refused."""
+@pytest.mark.parametrize("B,H,W,cin,k,s,n1,n2", [(2, 160, 160, 64, 3, 2, 128, 128), (1, 51, 37, 64, 3, 2, 128, 128), (3, 40, 24, 128, 3, 1, 128, 64),
+                                                 (2, 33, 20, 64, 1, 1, 128, 72), (1, 9, 9, 192, 3, 2, 128, 128),
+                                                 (2, 160, 160, 128, 3, 2, 256, 256), (1, 45, 37, 128, 3, 2, 256, 256), (2, 24, 40, 64, 3, 1, 256, 136),
+                                                 (1, 20, 20, 256, 3, 2, 256, 256)])
+def test_conv2d_chain_is_bit_identical_to_two_launches(dev, dtype, B, H, W, cin, k, s, n1, n2):
+    """cft_conv2d_chain (stride-2 Conv + the C3's packed cv1|cv2 in one kernel; the 128- / 256-channel tensor between them stays in
+    LDS): same values, roundings and k order as the two cft_conv2d launches -> bit-identical, for full tiles, pixel tails, n2 < n1,
+    other first-layer geometries (1x1, stride 1, the chunk-major K walk of 256 input channels), both tile forms (128 wide: weights of
+    the second layer resident; 256 wide: streamed); a channel-slice destination works; ineligible pairs are refused."""
     from msod_amd import ops
     x = to_dev_nhwc(_q(_rnd(B, cin, H, W, seed=31), dtype), dev, dtype)
-    pk1 = ops.pack_conv(_rnd(128, cin, k, k, seed=32) * (2.0 / (cin * k * k)) ** 0.5, _rnd(128, seed=33) * 0.1, dtype, s=s, device=dev)
-    pk2 = ops.pack_conv(_rnd(n2, 128, 1, 1, seed=34) * (2.0 / 128) ** 0.5, _rnd(n2, seed=35) * 0.1, dtype, device=dev)
+    pk1 = ops.pack_conv(_rnd(n1, cin, k, k, seed=32) * (2.0 / (cin * k * k)) ** 0.5, _rnd(n1, seed=33) * 0.1, dtype, s=s, device=dev)
+    pk2 = ops.pack_conv(_rnd(n2, n1, 1, 1, seed=34) * (2.0 / n1) ** 0.5, _rnd(n2, seed=35) * 0.1, dtype, device=dev)
     assert ops.conv2d_chain_ok(x, pk1, pk2)
     two = ops.conv2d(ops.conv2d(x, pk1, ops.ACT_SILU), pk2, ops.ACT_SILU)
     one = ops.conv2d_chain(x, pk1, pk2, ops.ACT_SILU)
@@ -244,7 +247,7 @@ def test_conv2d_chain_is_bit_identical_to_two_launches(dev, dtype, B, H, W, cin,
     torch.cuda.synchronize()
     assert torch.equal(one, two) and float(two.float().abs().max()) > 0.1
     assert torch.equal(sl, lin) and float(buf[:, :8].float().abs().max()) == 0.0 and float(buf[:, 8 + pk2.n:].float().abs().max()) == 0.0
-    pk_bad = ops.pack_conv(_rnd(64, cin, k, k, seed=36), None, dtype, s=s, device=dev)          # first layer not 128 wide
+    pk_bad = ops.pack_conv(_rnd(64, cin, k, k, seed=36), None, dtype, s=s, device=dev)          # first layer neither 128 nor 256 wide
     pk2_bad = ops.pack_conv(_rnd(n2, 64, 1, 1, seed=37), None, dtype, device=dev)
     assert not ops.conv2d_chain_ok(x, pk_bad, pk2_bad)
     with pytest.raises(ValueError):

@@ -1,5 +1,5 @@
-"""Per-pair timing of cft_conv2d_chain against the two cft_conv2d launches it replaces (stride-2 Conv 64 -> 128 + the C3's packed
-cv1|cv2 128 -> 128 at the bench shape), interleaved and warmed; HIP events on the launch stream.
+"""Per-pair timing of cft_conv2d_chain against the two cft_conv2d launches it replaces (stride-2 Conv 64 -> 128 / 128 -> 256 + the C3's
+packed cv1|cv2 at the bench shape), interleaved and warmed; HIP events on the launch stream.
   python tools/chain_bench.py [--batch 64] [--size 640]
 """
 import argparse
@@ -21,12 +21,12 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
-    for dtype in (torch.bfloat16, torch.float16):
-        H = args.size // 2
-        x = ops.new_nhwc(args.batch, H, H, 64, dtype, dev)
-        x.copy_(torch.randn(args.batch, 64, H, H, generator=g).to(dtype))
-        pk1 = ops.pack_conv(torch.randn(128, 64, 3, 3, generator=g) * 0.06, torch.randn(128, generator=g) * 0.1, dtype, s=2, device=dev)
-        pk2 = ops.pack_conv(torch.randn(128, 128, 1, 1, generator=g) * 0.12, torch.randn(128, generator=g) * 0.1, dtype, device=dev)
+    for dtype, (cin, n1, div) in ((d, c) for d in (torch.bfloat16, torch.float16) for c in ((64, 128, 2), (128, 256, 4))):
+        H = args.size // div
+        x = ops.new_nhwc(args.batch, H, H, cin, dtype, dev)
+        x.copy_(torch.randn(args.batch, cin, H, H, generator=g).to(dtype))
+        pk1 = ops.pack_conv(torch.randn(n1, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5, torch.randn(n1, generator=g) * 0.1, dtype, s=2, device=dev)
+        pk2 = ops.pack_conv(torch.randn(n1, n1, 1, 1, generator=g) * (2.0 / n1) ** 0.5, torch.randn(n1, generator=g) * 0.1, dtype, device=dev)
         mid = ops.conv2d(x, pk1, ops.ACT_SILU)
         out2 = ops.conv2d(mid, pk2, ops.ACT_SILU)
         out1 = ops.conv2d_chain(x, pk1, pk2, ops.ACT_SILU)
@@ -57,8 +57,8 @@ def main():
                 if rnd > 0:
                     best[name] = min(best.get(name, 1e9), us)
         M = args.batch * (H // 2) ** 2
-        fl = 2.0 * M * (128 * 576 + 128 * 128)
-        print(f"{str(dtype):16s} {args.batch} x 64ch {H}x{H} -> 128 -> 128 @ {H // 2}:  " +
+        fl = 2.0 * M * (n1 * 9 * cin + n1 * n1)
+        print(f"{str(dtype):16s} {args.batch} x {cin}ch {H}x{H} -> {n1} -> {n1} @ {H // 2}:  " +
               "   ".join(f"{k} {v:7.1f} us" for k, v in best.items()) +
               f"   chained = {best['chained'] / best['two launches']:.3f} x two launches, {fl / best['chained'] / 1e6:.0f} TFLOP/s")
 
