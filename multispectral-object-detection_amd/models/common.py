@@ -267,9 +267,35 @@ class C3(_Packed):
         head = cat[:, :c_]
         y = head
         n = len(self.m)
+        # Without shortcuts a Bottleneck's output has ONE reader, the next Bottleneck's 1x1 (reference models/common.py:108-109, :142):
+        # cv2[j] + cv1[j + 1] then run as one launch (ops.conv2d_chain) and the tensor between the two Bottlenecks never exists.
+        can = [self.chain and j + 1 < n and self._chainable(self.m[j], self.m[j + 1], head) for j in range(n)]
+        hidden = None              # cv1 output of Bottleneck j, already produced by the chained launch of Bottleneck j - 1
         for j, blk in enumerate(self.m):
-            y = blk(y, out=head if j == n - 1 else None)
+            dst = head if j == n - 1 else None
+            if hidden is None and not can[j]:
+                y = blk(y, out=dst)
+                continue
+            h = hidden if hidden is not None else blk.cv1(y)
+            if can[j]:
+                nxt = self.m[j + 1]
+                hidden = ops.conv2d_chain(h, blk.cv2._packed(h.dtype, h.device), nxt.cv1._packed(h.dtype, h.device), _act_code(nxt.cv1.act))
+            else:
+                hidden, y = None, blk.cv2(h, out=dst)
         return self.cv3(cat, out=out)
+
+    chain = True                   # Model.chain_convs switches it (A/B)
+
+    def _chainable(self, blk, nxt, y):
+        """``blk.cv2`` (3x3) and ``nxt.cv1`` (1x1) can run as one kernel on tensors shaped like ``y``: inference, no shortcut on either
+        (``blk``'s output is then read by ``nxt.cv1`` only), SiLU, and a geometry the chained kernel takes."""
+        if self.training or blk.add or nxt.add or not (isinstance(y, torch.Tensor) and y.is_cuda) or _act_code(blk.cv2.act) != ACT_SILU:
+            return False
+        if ops.bottleneck_fusable(y, blk.cv1._packed(y.dtype, y.device), blk.cv2._packed(y.dtype, y.device),
+                                  _act_code(blk.cv1.act), _act_code(blk.cv2.act)):
+            return False               # 64 / 128 channels: the patch-resident Bottleneck kernel is the better fusion
+        return ops.conv2d_chain_ok_geometry(y.shape[0], y.shape[2], y.shape[3], y.dtype, blk.cv2._packed(y.dtype, y.device),
+                                            nxt.cv1._packed(y.dtype, y.device))
 
 
 class SPP(nn.Module):

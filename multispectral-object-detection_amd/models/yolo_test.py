@@ -333,6 +333,21 @@ class Model(nn.Module):
         return plan
 
     # ---- CFT output fusion: both Add2 layers behind a GPT block and the Add that sums them run as ONE kernel ----------------
+    @property
+    def chain_convs(self):
+        """Run producer / pointwise-consumer layer pairs as one ``cft_conv2d_chain`` kernel where eligible (default): the Conv handed to
+        the C3 behind it (``chain_plan``) and, inside a C3 without shortcuts, ``Bottleneck[j].cv2`` + ``Bottleneck[j+1].cv1``.  ``False``
+        runs every layer as its own launch (A/B; bit-identical results)."""
+        return self.__dict__.get("_chain_convs", True)
+
+    @chain_convs.setter
+    def chain_convs(self, on):
+        self.__dict__["_chain_convs"] = bool(on)
+        for m in self.modules():
+            if isinstance(m, C3):
+                m.chain = bool(on)
+        self.__dict__.get("_graphs", {}).clear()        # a captured graph replays the launches of capture time
+
     def chain_plan(self):
         """Indices of the ``Conv`` layers whose output is read by exactly one layer, the ``C3`` right behind them (``f == -1``): yaml
         rows 1, 3, 6, 8, 13, 15 of the x3 configs (the convs in front of SPP or Concat do not qualify).  Such a conv is handed to its
@@ -438,7 +453,7 @@ class Model(nn.Module):
                     return m(x, out=buf[:, off:off + c])
         if cbufs is not None and isinstance(m, Concat) and m.i in cbufs:
             return m(x, out=cbufs[m.i])
-        if (cbufs is not None and not self.training and m.i in self.chain_plan() and self.__dict__.get("chain_convs", True)
+        if (cbufs is not None and not self.training and m.i in self.chain_plan() and self.chain_convs
                 and isinstance(x, torch.Tensor) and x.dtype in (torch.bfloat16, torch.float16)):
             return PendingConv(m, x)                 # left to the C3 behind it (one kernel for the conv and the C3's cv1|cv2)
         return m(x)

@@ -205,14 +205,20 @@ def conv2d(x, pk, act, residual=None, out=None, out_dtype=None):
     return out
 
 
+def conv2d_chain_ok_geometry(B, H, W, dtype, pk1, pk2):
+    """``conv2d_chain_ok`` from the input geometry alone ([B, pk1.cin, H, W] of ``dtype`` on the GPU)."""
+    if dtype not in (torch.bfloat16, torch.float16):
+        return False
+    if pk2.k != 1 or pk2.s != 1 or pk2.cin != pk1.n or pk2.kpad != pk1.n or pk1.n_valid != pk1.n:
+        return False
+    return bool(_lib.load().cft_conv2d_chain_ok(B, H, W, pk1.cin, pk1.n, pk1.kpad, pk1.k, pk1.s, pk2.n, _dt(dtype)))
+
+
 def conv2d_chain_ok(x, pk1, pk2):
     """True when ``conv2d_chain`` takes this pair: conv ``pk1`` (SiLU) then the pointwise conv ``pk2`` on its output (cft_conv2d_chain_ok)."""
-    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16)):
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.shape[1] == pk1.cin):
         return False
-    if pk2.k != 1 or pk2.s != 1 or pk2.cin != pk1.n or pk2.kpad != pk1.n or pk1.n_valid != pk1.n or x.shape[1] != pk1.cin:
-        return False
-    B, _, H, W = x.shape
-    return bool(_lib.load().cft_conv2d_chain_ok(B, H, W, pk1.cin, pk1.n, pk1.kpad, pk1.k, pk1.s, pk2.n, _dt(x.dtype)))
+    return conv2d_chain_ok_geometry(x.shape[0], x.shape[2], x.shape[3], x.dtype, pk1, pk2)
 
 
 def conv2d_chain(x, pk1, pk2, act2, out=None):

@@ -424,7 +424,8 @@ def test_cft_output_fusion_matches_the_three_launch_path(dev, dtype):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 def test_conv_c3_chain_is_bit_identical_to_the_layerwise_walk(dev, dtype):
     """Model.chain_plan: the stride-2 Conv in front of every backbone C3 is handed to that C3 un-run; where the pair is eligible
-    (yolov5l: rows 1-2 / 6-7, 64 -> 128 channels, and rows 3-4 / 8-9, 128 -> 256) both run as one cft_conv2d_chain kernel.  Same arithmetic: the detections are
+    (yolov5l: rows 1-2 / 6-7, 64 -> 128 channels, and rows 3-4 / 8-9, 128 -> 256) both run as one cft_conv2d_chain kernel; so do cv2 of Bottleneck j and cv1 of
+    Bottleneck j + 1 inside the head's 256-channel C3s, which have no shortcuts.  Same arithmetic: the detections are
     bit-identical to the walk that runs every layer on its own, on one lane or two, and under HIP-graph replay."""
     from msod_amd import ops
     from msod_amd.utils.seeded import seeded_inputs
@@ -449,7 +450,8 @@ def test_conv_c3_chain_is_bit_identical_to_the_layerwise_walk(dev, dtype):
         model.capture(2, 192, 256)
         pred_g = model(x, x2)[0].clone()
     torch.cuda.synchronize()
-    assert sum(1 for rec in log if rec[0].startswith("conv_chain_")) == 4          # rows 1-2, 3-4 (RGB) and 6-7, 8-9 (IR)
+    # rows 1-2, 3-4 (RGB), 6-7, 8-9 (IR); and inside the two 256-channel C3s of the head (no shortcuts) cv2[j] + cv1[j + 1], j = 0, 1
+    assert sum(1 for rec in log if rec[0].startswith("conv_chain_k3s2")) == 4 and sum(1 for rec in log if rec[0].startswith("conv_chain_k3s1")) == 4
     assert torch.equal(pred_c, pred_u) and torch.equal(pred_c2, pred_u) and torch.equal(pred_g, pred_u)
     assert all(torch.equal(a, b) for a, b in zip(raw_c, raw_u))
 
