@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
     // (every wave is past the barrier that ended the last K step: both staging buffers are free)
     // K steps of the second GEMM = 64-channel images of this tile (host: N == BN).  Two images: they and the second layer's weights
     // take the places of the staging buffers.  Four (256-wide tile): the images fill all of the staging area and the weights stream
-    // through ONE extra buffer behind it, a K step at a time (launch_conv sizes the allocation).
+    // through ONE extra buffer behind it and through the images already consumed (launch_conv sizes the allocation).
     constexpr int NK2 = BN / 64;
     constexpr bool W2_RESIDENT = NK2 <= 2;
     unsigned char* sB2 = W2_RESIDENT ? sB : smem + NK2 * A_BYTES;
@@ -329,15 +329,21 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
 #pragma unroll
       for (int k2 = 0; k2 < NK2; ++k2) { CFT_COMPUTE_STEP_AT(sA + k2 * A_BYTES, sB2 + k2 * B_BYTES) }
     } else {
-#pragma unroll 1
-      for (int k2 = 0; k2 < NK2; ++k2) {
-        __syncthreads();                                   // this K step's weights have landed (first pass: and the images are written)
-        CFT_COMPUTE_STEP_AT(sA + k2 * A_BYTES, sB2)
-        if (k2 + 1 < NK2) {
-          __syncthreads();                                 // every wave is done with the buffer
-          CFT_LOAD_W2(k2 + 1, sB2)
-        }
-      }
+      // Four images I0..I3, one extra buffer X.  An image is dead once its K step is done, so the later weight steps land in dead
+      // images: only the second step's weights are waited for with nothing to do (X and I0 are both free only after step 0).
+      static_assert(NK2 == 4 && B_BYTES <= A_BYTES, "chained GEMM: streamed second-layer weights are scheduled for four K steps");
+      __syncthreads();                                     // images written, W2 step 0 in X
+      CFT_COMPUTE_STEP_AT(sA, sB2)
+      __syncthreads();                                     // X and I0 are free
+      CFT_LOAD_W2(1, sB2)
+      CFT_LOAD_W2(2, sA)
+      __syncthreads();                                     // both landed
+      CFT_COMPUTE_STEP_AT(sA + A_BYTES, sB2)
+      __syncthreads();                                     // I1 is free
+      CFT_LOAD_W2(3, sA + A_BYTES)                         // lands under step 2
+      CFT_COMPUTE_STEP_AT(sA + 2 * A_BYTES, sA)
+      __syncthreads();
+      CFT_COMPUTE_STEP_AT(sA + 3 * A_BYTES, sA + A_BYTES)
     }
 #undef CFT_LOAD_W2
     __syncthreads();

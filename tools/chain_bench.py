@@ -21,11 +21,13 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
-    for dtype, (cin, n1, div) in ((d, c) for d in (torch.bfloat16, torch.float16) for c in ((64, 128, 2), (128, 256, 4))):
+    # (input channels, first layer's width, input size = image size / div, stride): the two backbone pairs, and cv2 of Bottleneck j +
+    # cv1 of Bottleneck j + 1 in the head's 256-channel C3s
+    for dtype, (cin, n1, div, st) in ((d, c) for d in (torch.bfloat16, torch.float16) for c in ((64, 128, 2, 2), (128, 256, 4, 2), (256, 256, 16, 1))):
         H = args.size // div
         x = ops.new_nhwc(args.batch, H, H, cin, dtype, dev)
         x.copy_(torch.randn(args.batch, cin, H, H, generator=g).to(dtype))
-        pk1 = ops.pack_conv(torch.randn(n1, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5, torch.randn(n1, generator=g) * 0.1, dtype, s=2, device=dev)
+        pk1 = ops.pack_conv(torch.randn(n1, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5, torch.randn(n1, generator=g) * 0.1, dtype, s=st, device=dev)
         pk2 = ops.pack_conv(torch.randn(n1, n1, 1, 1, generator=g) * (2.0 / n1) ** 0.5, torch.randn(n1, generator=g) * 0.1, dtype, device=dev)
         mid = ops.conv2d(x, pk1, ops.ACT_SILU)
         out2 = ops.conv2d(mid, pk2, ops.ACT_SILU)
@@ -56,9 +58,9 @@ def main():
                 us = e0.elapsed_time(e1) * 1e3 / args.iters
                 if rnd > 0:
                     best[name] = min(best.get(name, 1e9), us)
-        M = args.batch * (H // 2) ** 2
+        M = args.batch * (H // st) ** 2
         fl = 2.0 * M * (n1 * 9 * cin + n1 * n1)
-        print(f"{str(dtype):16s} {args.batch} x {cin}ch {H}x{H} -> {n1} -> {n1} @ {H // 2}:  " +
+        print(f"{str(dtype):16s} {args.batch} x {cin}ch {H}x{H} -> {n1} -> {n1} @ {H // st}:  " +
               "   ".join(f"{k} {v:7.1f} us" for k, v in best.items()) +
               f"   chained = {best['chained'] / best['two launches']:.3f} x two launches, {fl / best['chained'] / 1e6:.0f} TFLOP/s")
 
