@@ -106,7 +106,9 @@ def traffic_from_profile(args, n_launch, abytes):
     t = json.load(open(path))
     if (t.get("config"), t.get("batch"), t.get("size"), t.get("dtype")) != (args.config, args.batch, args.size, args.dtype):
         return None
+    # forward_kernels_*: the kernels of a forward; all_kernels_* (what rounds 1-3 quoted) also holds the process's one-time set-up traffic
     return {"bytes_per_launch": t["gemm_bytes_per_forward"] / n_launch, "algorithmic_bytes_per_launch": abytes / n_launch,
+            "forward_kernels_bytes_per_forward": t.get("forward_kernels_bytes_per_forward", t.get("all_kernels_bytes_per_forward")),
             "all_kernels_bytes_per_forward": t.get("all_kernels_bytes_per_forward"),
             "source": f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
 
@@ -456,8 +458,8 @@ def main():
         tr = rl["traffic"] or {}
         floors = {"mfma_ms": round((flops + sum(v[1] for v in aux.values())) / (peak * 1e12) * 1e3, 3),
                   "hbm_ms_algorithmic": round(alg_bytes / (HBM_ACHIEVABLE_TBPS * 1e12) * 1e3, 3),
-                  "hbm_ms_counters": round(tr["all_kernels_bytes_per_forward"] / (HBM_ACHIEVABLE_TBPS * 1e12) * 1e3, 3) if tr.get("all_kernels_bytes_per_forward") else None,
-                  "hbm_ms_counters_at_measured_mixed_rate": round(tr["all_kernels_bytes_per_forward"] / (HBM_MIXED_TBPS * 1e12) * 1e3, 3) if tr.get("all_kernels_bytes_per_forward") else None,
+                  "hbm_ms_counters": round(tr["forward_kernels_bytes_per_forward"] / (HBM_ACHIEVABLE_TBPS * 1e12) * 1e3, 3) if tr.get("forward_kernels_bytes_per_forward") else None,
+                  "hbm_ms_counters_at_measured_mixed_rate": round(tr["forward_kernels_bytes_per_forward"] / (HBM_MIXED_TBPS * 1e12) * 1e3, 3) if tr.get("forward_kernels_bytes_per_forward") else None,
                   "algorithmic_gbytes_per_step": round(alg_bytes / 1e9, 2),
                   "hbm_rate": f"{HBM_ACHIEVABLE_TBPS} TB/s achievable (spec {HBM_SPEC_TBPS}; read + write streams measure {HBM_MIXED_TBPS} on this chip, profiles/r04_hbm_rw_microbench.txt: informational field only); algorithmic bytes cover the GEMM family and the CFT pointwise kernels "
                               "(SPP / concat copies / Add / Detect decode are not logged: < 2 % of the bytes)"}
