@@ -6,6 +6,7 @@ relative to the output scale and is stated in ``helpers.tol``.
 """
 import math
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -252,6 +253,35 @@ def test_conv2d_chain_is_bit_identical_to_two_launches(dev, dtype, B, H, W, cin,
     assert not ops.conv2d_chain_ok(x, pk_bad, pk2_bad)
     with pytest.raises(ValueError):
         ops.conv2d_chain(x, pk_bad, pk2_bad, ops.ACT_SILU)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_conv2d_chain_random_geometries(dev, seed):
+    """Seeded sweep over what cft_conv2d_chain_ok accepts (first layer 1x1 / 3x3 / 5x5, stride 1 / 2, 64..320 input channels, odd image
+    sizes, batch 1..5, ragged second-layer widths, both tile forms, both dtypes): bit-identical to the two launches, and within the
+    16-bit tolerance of the fp32 torch reference of the same two layers."""
+    from msod_amd import ops
+    rng = np.random.RandomState(1000 + seed)
+    dtype = (torch.bfloat16, torch.float16)[seed % 2]
+    n1 = (128, 256)[int(rng.randint(2))]
+    k = (1, 3, 3, 5)[int(rng.randint(4))]
+    s = int(rng.randint(1, 3))
+    cin = 64 * int(rng.randint(1, 6 if k < 5 else 3))
+    B, H, W = int(rng.randint(1, 6)), int(rng.randint(5, 60)), int(rng.randint(5, 60))
+    n2 = 8 * int(rng.randint(1, n1 // 8 + 1))
+    xf = _q(_rnd(B, cin, H, W, seed=seed), dtype)
+    w1, b1 = _rnd(n1, cin, k, k, seed=seed + 1) * (2.0 / (cin * k * k)) ** 0.5, _rnd(n1, seed=seed + 2) * 0.1
+    w2, b2 = _rnd(n2, n1, 1, 1, seed=seed + 3) * (2.0 / n1) ** 0.5, _rnd(n2, seed=seed + 4) * 0.1
+    x = to_dev_nhwc(xf, dev, dtype)
+    pk1, pk2 = ops.pack_conv(w1, b1, dtype, s=s, device=dev), ops.pack_conv(w2, b2, dtype, device=dev)
+    assert ops.conv2d_chain_ok(x, pk1, pk2), (n1, k, s, cin, B, H, W, n2)
+    one = ops.conv2d_chain(x, pk1, pk2, ops.ACT_SILU)
+    two = ops.conv2d(ops.conv2d(x, pk1, ops.ACT_SILU), pk2, ops.ACT_SILU)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two), (n1, k, s, cin, B, H, W, n2)
+    mid = _q(F.silu(F.conv2d(xf, _q(w1, dtype), b1, stride=s, padding=k // 2)), dtype)
+    ref = F.silu(F.conv2d(mid, _q(w2, dtype), b2))
+    assert rel_err(to_cpu_f32(one), ref) < tol(dtype)
 
 
 @pytest.mark.parametrize("C", [64, 256, 320, 1024, 1280])

@@ -110,6 +110,33 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(raw, name), name
 
 
+def test_conv2d_chain_eligibility_is_a_host_decision():
+    """cft_conv2d_chain_ok (no GPU): the chained kernel takes a first layer of exactly 128 or 256 output channels on the uniform K walk
+    (cin % 64 == 0, no K padding), 16-bit operands, and a pointwise second layer no wider than the first - the 64 -> 128 and 128 -> 256
+    stride-2 convs + C3.cv1|cv2 of yolov5l (reference models/common.py:45-50, 141-143) and cv2[j] + cv1[j+1] of its 256-channel head
+    C3s; not the 256 -> 512 pair, yolov5x's 80 / 160-channel layers, fp32, or a padded K.  An ineligible pair is refused by the launcher."""
+    lib = _lib.load()
+    BF16, F32, F16 = 0, 1, 2
+    ok = lib.cft_conv2d_chain_ok
+    assert ok(64, 320, 320, 64, 128, 576, 3, 2, 128, BF16) == 1            # yaml rows 1-2 / 6-7
+    assert ok(64, 160, 160, 128, 256, 1152, 3, 2, 256, F16) == 1           # rows 3-4 / 8-9
+    assert ok(64, 40, 40, 256, 256, 2304, 3, 1, 256, BF16) == 1            # head C3: cv2[j] + cv1[j+1]
+    assert ok(1, 9, 9, 64, 128, 64, 1, 1, 8, BF16) == 1                    # any size, 1x1 first layer, narrow second layer
+    assert ok(64, 80, 80, 256, 512, 2304, 3, 2, 512, BF16) == 0            # 512 channels do not fit a tile
+    assert ok(16, 640, 640, 80, 160, 720, 3, 2, 160, BF16) == 0            # yolov5x widths
+    assert ok(64, 320, 320, 64, 128, 576, 3, 2, 128, F32) == 0             # 16-bit only
+    assert ok(64, 320, 320, 64, 128, 640, 3, 2, 128, BF16) == 0            # padded K
+    assert ok(64, 320, 320, 32, 128, 288, 3, 2, 128, BF16) == 0            # cin % 64
+    assert ok(64, 320, 320, 64, 128, 576, 3, 2, 136, BF16) == 0            # second layer wider than the first
+    assert ok(64, 320, 320, 64, 128, 576, 3, 2, 100, BF16) == 0            # n2 % 8
+    assert ok(0, 320, 320, 64, 128, 576, 3, 2, 128, BF16) == 0 and ok(64, 320, 320, 64, 128, 576, 2, 2, 128, BF16) == 0
+    # null / ineligible arguments are refused before any launch
+    st = lib.cft_conv2d_chain(None, None, None, None, None, None, 1, 8, 8, 64, 64, 0, 128, 576, 3, 2, 128, 128, 0, 1, BF16, None)
+    assert st == -1 and b"null pointer" in lib.cft_last_error()
+    st = lib.cft_conv2d_chain(4096, 4096, None, 4096, None, 4096, 1, 8, 8, 64, 64, 0, 512, 576, 3, 2, 128, 128, 0, 1, BF16, None)
+    assert st == -1 and b"not eligible" in lib.cft_last_error()
+
+
 def test_bad_arguments_return_error_codes_without_gpu():
     lib = _lib.load()
     st = lib.cft_conv2d(None, None, None, None, None, 1, 8, 8, 8, 8, 0, 8, 64, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, None)
