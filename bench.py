@@ -202,6 +202,39 @@ def parity_at_bench_shape(dtype_name, got_raw, want_raw, ref16_raw=None, n_ref=0
     return out
 
 
+def survey_weights_parity(cfg, args, dev, dtype, rgb, ir, n_pairs=2):
+    """The benchmarked configuration once more, on the weights SURVEY.md section 8c / BASELINE.md section 2 literally prescribe
+    (utils/seeded.survey_state_dict: torch.manual_seed(0) constructor weights, BatchNorm statistics / affine and pos_emb
+    randomised; pinned to the reference's constructor and forward in tests/test_oracle_golden.py): same batch, shape, compute
+    dtype and HIP-graph replay; the first ``n_pairs`` pairs vs the fp32 oracle, north_star's literal bound (1e-2 in sigmoid space for
+    the 16-bit types, 1e-3 on raw logits for fp32)."""
+    from msod_amd.utils.seeded import survey_state_dict
+    from oracle.cft_oracle import OracleModel
+    m2 = Model(cfg)
+    m2.load_state_dict(survey_state_dict(lambda: Model(cfg), seed=0))
+    m2.fuse()
+    sd2 = {k: v.clone() for k, v in m2.state_dict().items()}
+    m2 = m2.to(dev).set_compute_dtype(dtype)
+    with torch.no_grad():
+        if args.no_graph:
+            _, raw = m2.forward_once(rgb, ir)
+        else:
+            m2.capture(args.batch, args.size, args.size)
+            _, raw = m2(rgb, ir)
+        torch.cuda.synchronize()
+        got = [r[:n_pairs].float().cpu() for r in raw]
+    m2.release_graphs()
+    _, want = OracleModel(cfg)(sd2, rgb[:n_pairs].cpu(), ir[:n_pairs].cpu())
+    g, w = _flat(got), _flat(want)
+    f32 = dtype == torch.float32
+    err = (g - w).abs().max().item() if f32 else (g.sigmoid() - w.sigmoid()).abs().max().item()
+    bound = 1e-3 if f32 else 1e-2
+    return {"weights": "SURVEY.md 8c recipe (utils/seeded.survey_state_dict)", "pairs": n_pairs, "check": BOUNDS[args.dtype][0],
+            "gate": "north_star's literal bound, asserted outright", "max_err": round(err, 6), "bound": bound,
+            "meets_north_star_bound": bool(err <= bound), "logit_std": round(w.std().item(), 4),
+            "rms_logit_err_over_std": round(((g - w).pow(2).mean().sqrt() / w.std()).item(), 6), "ok": bool(err <= bound)}
+
+
 class ShaderClockProbe:
     """Shader clock the SIMDs run at while a leg is in flight, read from inside the GPU: every ``period`` seconds a thread
     launches ``cft_clock_probe`` (one wave, ``spin_us`` of the constant-rate wall clock) on its own stream next to the forward;
@@ -286,13 +319,19 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2, help="forwards in flight (own graphs, buffers and streams each); 1 = one at a time")
     ap.add_argument("--force-gather", action="store_true", help="N = 1: run the detection all-gather anyway (RCCL with world size 1, OverlappedGather "
                     "inside the timed steps) and report multi_gpu_selfcheck - exercises the N > 1 step mode on the one GPU of a box")
+    ap.add_argument("--depth-first", default="", help="CHUNKS[,ROWS]: Model.depth_first - the image-only prefix of each backbone sub-batch by sub-batch "
+                    "(Infinity-Cache residency); empty = layer by layer over the whole batch")
     ap.add_argument("--conv-variant", type=int, default=0, help="A/B runs: cft_set_conv_variant() for the whole process (0 = automatic)")
     args = ap.parse_args()
 
+    relaunch = D.launch_command(os.path.abspath(__file__), args.gpus, sys.argv[1:])
+    if relaunch is not None:       # --gpus N > 1 without a launcher: N ranks under torch.distributed.run (never one rank posing as N)
+        log("re-launching: " + " ".join(relaunch))
+        os.execvp(relaunch[0], relaunch)
     exit_code = 0
     rank, world, local = D.init_from_env(force=args.force_gather)
     gathering = world > 1 or args.force_gather
-    if world != args.gpus and world > 1:
+    if world != args.gpus and (world > 1 or args.gpus > 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
@@ -311,6 +350,9 @@ def main():
     model.plan_concats = not args.no_concat_plan
     model.fuse_cft_outputs = not args.no_cft_fusion
     model.chain_convs = not args.no_conv_chain
+    if args.depth_first:
+        df = [int(v) for v in args.depth_first.split(",")]
+        model.depth_first = (df[0], df[1] if len(df) > 1 else None)
     rgb, ir = seeded_inputs(args.batch, args.size, args.size, seed=rank)
     rgb, ir = rgb.to(dev), ir.to(dev)
 
@@ -396,11 +438,24 @@ def main():
         n_launch, flops, secs, fam, ovh, abytes, aux = gemm_family_time(model, rgb, ir)
         log(f"gemm family: {n_launch} launches, {secs * 1e3:.2f} ms, {flops / secs / 1e12:.1f} TFLOP/s")
         top = sorted(fam.items(), key=lambda kv: -kv[1][2])[:6]
+        peak = PEAK_F32_TFLOPS if dtype == torch.float32 else PEAK_BF16_TFLOPS     # bf16 and fp16 MFMA have the same dense peak
+
+        def family_row(v):
+            """Per-shape floors (DESIGN.md section 9's additive law as data): per launch, the MFMA time of the shape's
+            algorithmic FLOPs at the dense peak, the HBM time of its algorithmic bytes (inputs once + outputs once + weights) at the
+            achievable HBM rate, and measured / (mfma + hbm)."""
+            n, us = v[0], v[2] / v[0] * 1e6
+            mfma_us, hbm_us = v[1] / n / (peak * 1e12) * 1e6, v[3] / n / (HBM_ACHIEVABLE_TBPS * 1e12) * 1e6
+            return {"launches": n, "gflop": v[1] / 1e9, "ms": v[2] * 1e3, "tflops": v[1] / v[2] / 1e12, "mbytes_per_launch": round(v[3] / n / 1e6, 2),
+                    "us_per_launch": round(us, 2), "mfma_us": round(mfma_us, 2), "hbm_us": round(hbm_us, 2),
+                    "measured_over_mfma_plus_hbm": round(us / (mfma_us + hbm_us), 3), "measured_over_max_floor": round(us / max(mfma_us, hbm_us), 3),
+                    "excess_ms": round((us - (mfma_us + hbm_us)) * n * 1e-3, 3)}
+        fam_rows = {k: family_row(v) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])}
         if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
             with open(os.path.join(ROOT, "gpurun_out", "bench_families.json"), "w") as fh:
-                json.dump({k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3, "tflops": v[1] / v[2] / 1e12}
-                           for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])}, fh, indent=1)
-        peak = PEAK_F32_TFLOPS if dtype == torch.float32 else PEAK_BF16_TFLOPS     # bf16 and fp16 MFMA have the same dense peak
+                json.dump({**fam_rows, **{k: family_row(v) for k, v in aux.items()}}, fh, indent=1)
+        # the five shapes that lose the most time against their own floors (time above mfma + hbm, summed over their launches)
+        worst = sorted(fam_rows.items(), key=lambda kv: -kv[1]["excess_ms"])[:5]
         achieved = flops / secs / 1e12
         split = {}
         for kind in ("conv", "linear"):     # convolutions vs the nn.Linear GEMMs of the CFT (GPT) blocks
@@ -434,6 +489,7 @@ def main():
                        "pairs_per_gpu": args.batch, "image_size": args.size, "parallelism": f"batch-shard x{world}",
                        "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap, "forwards_in_flight": k_fly, "env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
                        **({"stream_group_probe_ms_per_step": stream_probe_ms} if stream_probe_ms else {}),
+                       **({"depth_first": args.depth_first} if args.depth_first else {}),
                        **({"conv_variant": args.conv_variant} if args.conv_variant else {})},
             "sustained": sustained, "single_in_flight": single, "multi_gpu_selfcheck": selfcheck,
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear family; incl. the dedicated Focus kernel and the fused 64- / 128-channel Bottleneck kernels: 2 + 27 launches of the cfg3 forward)",
@@ -448,7 +504,10 @@ def main():
                          "by_block": {"backbone_head_convs": split.get("conv"), "cft_linears": split.get("linear"),
                                       "cft_block_whole": cft_block},
                          "top_shapes": [{"shape": k, "launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
-                                         "ms": round(v[2] * 1e3, 3)} for k, v in top]},
+                                         "ms": round(v[2] * 1e3, 3)} for k, v in top],
+                         "worst_shapes_vs_own_floors": [{"shape": k, "launches": r["launches"], "us_per_launch": r["us_per_launch"], "mfma_us": r["mfma_us"],
+                                                         "hbm_us": r["hbm_us"], "measured_over_mfma_plus_hbm": r["measured_over_mfma_plus_hbm"],
+                                                         "excess_ms": r["excess_ms"]} for k, r in worst]},
         }
         # Both floors of the whole step: the matrix floor at the dense peak and the HBM floor on the step's own bytes
         # (algorithmic = every logged kernel's inputs once + outputs once; counters = the PMC profile of the same configuration).  The
@@ -531,6 +590,14 @@ def main():
             line["parity_green_dtype"] = green[0] if green else None
             if line["parity_green_dtype"] == "f16" and "f16" in line:
                 line["parity_green_value"] = line["f16"]["value"]
+            line["parity_weights"] = "utils/seeded.seeded_state_dict (deliberately lively stress weights: activations O(1) through the depth)"
+            if world == 1:
+                # the contract's own weights: the timed dtype, literal bound; a miss fails the run like any parity miss
+                line["parity_at_bench_shape_survey_weights"] = sp = survey_weights_parity(cfg, args, dev, dtype, rgb, ir)
+                ok = ok and sp["ok"]
+                if sp["meets_north_star_bound"]:
+                    line["parity_green_dtype_survey_weights"] = args.dtype
+                log(f"survey-weights parity: {sp}")
         print(json.dumps(line), flush=True)
         if not ok:
             log("PARITY FAILURE at the benchmarked shape - see parity_at_bench_shape in the line above")

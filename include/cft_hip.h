@@ -80,7 +80,8 @@ int cft_conv2d_chain(const void* x, const void* w1, const float* bias1, const vo
                      int B, int H, int W, int cin, int ldx, int xoff,
                      int n1, int kpad1, int ksize, int stride, int n2,
                      int ldy, int yoff, int act2, int dtype, void* stream);
-int cft_conv2d_chain_ok(int B, int H, int W, int cin, int n1, int kpad1, int ksize, int stride, int n2, int dtype);
+/* 1 when cft_conv2d_chain accepts the pair (it runs the launcher's own validation, incl. the 2^31-element limits on the ldx / ldy extents). */
+int cft_conv2d_chain_ok(int B, int H, int W, int cin, int ldx, int n1, int kpad1, int ksize, int stride, int n2, int ldy, int dtype);
 
 /*
  * Bottleneck as one kernel (models/common.py:99-109 with e = 1.0, the form C3 uses :138):

@@ -588,12 +588,14 @@ extern "C" int cft_conv2d_chain(const void* x, const void* w1, const float* bias
   return CFT_EINVAL;
 }
 
-// 1 if cft_conv2d_chain takes this pair of layers (first layer: its cft_conv2d geometry, SiLU; second: pointwise, n2 outputs), else 0.
-extern "C" int cft_conv2d_chain_ok(int B, int H, int W, int cin, int n1, int kpad1, int ksize, int stride, int n2, int dtype) {
-  if (!(B > 0 && H > 0 && W > 0 && cin > 0 && n1 > 0 && (ksize == 1 || ksize == 3 || ksize == 5) && stride >= 1 && cft_is_dtype(dtype))) return 0;
-  const int pad = ksize / 2;
-  const long Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+// 1 if cft_conv2d_chain takes this pair of layers (first layer: its cft_conv2d geometry, SiLU; second: pointwise, n2 outputs; ldx / ldy: channels
+// per pixel of the input / output buffers), else 0.  Runs the launcher's OWN validation (fill_conv_params + chain_ok) on dummy pointers, so
+// "ok" and "cft_conv2d_chain accepts" cannot drift apart (the 2^31-element extents were missing here).
+extern "C" int cft_conv2d_chain_ok(int B, int H, int W, int cin, int ldx, int n1, int kpad1, int ksize, int stride, int n2, int ldy, int dtype) {
+  if (!cft_is_dtype(dtype) || n2 <= 0 || n2 % 8 != 0) return 0;
+  static const char dummy = 0;
   ConvParams p;
-  p.M = (int)((long)B * Ho * Wo); p.N = n1; p.Cin = cin; p.Kpad = kpad1; p.K = ksize * ksize * cin;
-  return (long)B * Ho * Wo < (1L << 31) && chain_ok(p, n2, dtype) ? 1 : 0;
+  const int rc = fill_conv_params(p, &dummy, &dummy, nullptr, nullptr, (void*)&dummy, B, H, W, cin, ldx, 0, n1, kpad1, ksize, stride,
+                                  ldy, 0, 0, 0, CFT_ACT_SILU, dtype, dtype, dtype);
+  return rc == CFT_OK && ldy >= n2 && ldx >= cin && chain_ok(p, n2, dtype) ? 1 : 0;
 }

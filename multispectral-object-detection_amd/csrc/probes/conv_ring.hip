@@ -2,7 +2,7 @@
 // to conv_gemm_kernel and was measured SLOWER than the 16-wave kernel on every layer shape of the forward (profiles/r04_gemm_experiments.md),
 // so it is compiled into the PROBE build only (tools/build_probes.sh, -DCFT_PROBES: variants 90 / 91 / 190 / 290 / 1690 of
 // cft_set_conv_variant); the product library holds the stub at the end of this file.
-#include "conv_common.h"
+#include "../conv_common.h"
 
 #ifdef CFT_PROBES
 

@@ -37,6 +37,31 @@ def init_from_env(backend=None, force=False):
     return rank, world, local
 
 
+def launch_command(script, gpus, argv, env=None, visible_devices=None, python=None):
+    """What ``bench.py --gpus N`` does when it is started WITHOUT a launcher: N > 1 ranks cannot be one process,
+    so the script re-executes itself under ``python -m torch.distributed.run`` - the reference's launch convention
+    (utils/aws/resume.py:31 ``torch.distributed.launch``, train.py:989-995: one process per GPU, RANK / WORLD_SIZE from the env) -
+    instead of silently timing one rank and reporting ``n_gpus: 1``.
+
+    Returns None when no re-launch is needed (N == 1, or WORLD_SIZE already set by a launcher), else the argv list to exec.
+    Raises SystemExit when fewer than N devices are visible."""
+    import sys
+    env = os.environ if env is None else env
+    if gpus <= 1 or "WORLD_SIZE" in env:
+        return None
+    if visible_devices is None:
+        visible_devices = torch.cuda.device_count()
+    if visible_devices < gpus:
+        raise SystemExit(f"--gpus {gpus}: only {visible_devices} GPU(s) visible to this process; refusing to report a {gpus}-GPU number "
+                         "from fewer devices")
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script] + list(argv)
+
+
 def shard_bounds(n, rank, world):
     """Contiguous shard [lo, hi) of ``n`` items for ``rank``; the first n % world ranks get one extra."""
     base, rem = divmod(n, world)

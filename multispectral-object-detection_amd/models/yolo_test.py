@@ -348,6 +348,75 @@ class Model(nn.Module):
                 m.chain = bool(on)
         self.__dict__.get("_graphs", {}).clear()        # a captured graph replays the launches of capture time
 
+    # Executor switches that change WHICH launches a walk issues: a captured graph replays the launches of capture time, so every
+    # setter drops the graphs (ADVICE r4: an A/B flipped after capture() used to compare a path against itself).
+    def _switch(name, default, doc):      # noqa: N805 - class-body helper
+        def get(self):
+            return self.__dict__.get("_" + name, default)
+
+        def set_(self, v):
+            self.__dict__["_" + name] = v
+            self.__dict__.get("_graphs", {}).clear()
+        return property(get, set_, doc=doc)
+
+    fuse_cft_outputs = _switch("fuse_cft_outputs", True, "Run the two Add2 layers behind a GPT block and the Add that sums them as one kernel (cft_fusion_plan).")
+    plan_concats = _switch("plan_concats", True, "Let Conv / C3 / Add layers that feed a head Concat write straight into their slice of its buffer (concat_plan).")
+    depth_first = _switch("depth_first", None,
+                          "None, or (chunks, rows): run the image-only prefix of each backbone (Focus -> Conv -> C3 -> ..., ``prefix_segments``) "
+                          "DEPTH-FIRST over ``chunks`` sub-batches - all of its (at most ``rows``) layers for pairs [0, B/chunks), then for the next "
+                          "sub-batch, ... - so that a layer reads what its producer just wrote while those bytes are still in the 256-MiB Infinity "
+                          "Cache instead of HBM (at 64 pairs the P1 / P2 tensors are 420 - 840 MB each).  Per-image arithmetic is unchanged: "
+                          "bit-identical outputs.  Inference only (BatchNorm batch statistics span the batch).")
+    del _switch
+
+    def prefix_segments(self, max_rows=None):
+        """[(i0, i1)]: maximal runs of layers that depend on ONE image batch only - a ``Focus`` fed by ``x`` (row 0) or ``x2`` (``f == -4``)
+        followed by ``f == -1`` Conv / C3 rows whose outputs have exactly one reader, the next row - cut to ``max_rows`` layers and
+        to end on a C3 (a trailing Conv would be a ``PendingConv`` of a C3 outside the segment).  x3 configs: rows 0-4 and 5-9."""
+        layers = list(self.model)
+        readers = {}
+        for j, m in enumerate(layers):
+            if m.f == -4 or j == 0:
+                continue
+            for f in ([m.f] if isinstance(m.f, int) else m.f):
+                readers.setdefault(j - 1 if f == -1 else f % j, set()).add(j)
+        planned = self.concat_plan()
+        segs = []
+        for i0, m in enumerate(layers):
+            if not isinstance(m, Focus) or not (i0 == 0 or m.f == -4):
+                continue
+            i1 = i0
+            while (i1 + 1 < len(layers) and layers[i1 + 1].f == -1 and type(layers[i1 + 1]) in (Conv, C3) and readers.get(i1) == {i1 + 1}
+                   and (i1 + 1) not in planned and (max_rows is None or i1 + 1 - i0 < max_rows)):
+                i1 += 1
+            while i1 > i0 and type(layers[i1]) is not C3:
+                i1 -= 1
+            if i1 > i0:
+                segs.append((i0, i1))
+        return segs
+
+    def _run_segment(self, seg, img, cbufs, chunks):
+        """Layers ``seg = (i0, i1)`` depth-first over ``chunks`` sub-batches of the image batch ``img``; returns the last layer's output
+        for the whole batch (each sub-batch's C3 writes its batch slice of it)."""
+        i0, i1 = seg
+        layers = self.model
+        B = img.shape[0]
+        full = None
+        for c in range(chunks):
+            b0, b1 = B * c // chunks, B * (c + 1) // chunks
+            if b1 == b0:
+                continue
+            x = layers[i0](img[b0:b1])
+            for i in range(i0 + 1, i1):
+                x = self._run_layer(layers[i], x, None, cbufs)
+            shape = x.shape                                   # (PendingConv knows its output shape without running)
+            if full is None:
+                c2 = layers[i1].cv3.conv.out_channels
+                dt = x.x.dtype if isinstance(x, PendingConv) else x.dtype
+                full = ops.new_nhwc(B, shape[2], shape[3], c2, dt, img.device)
+            layers[i1](x, out=full[b0:b1])
+        return full
+
     def chain_plan(self):
         """Indices of the ``Conv`` layers whose output is read by exactly one layer, the ``C3`` right behind them (``f == -1``): yaml
         rows 1, 3, 6, 8, 13, 15 of the x3 configs (the convs in front of SPP or Concat do not qualify).  Such a conv is handed to its
@@ -406,6 +475,8 @@ class Model(nn.Module):
         p0, p1 = x[1][0], x[1][1]
         if not (isinstance(p0, PendingBilinear) and isinstance(p1, PendingBilinear) and p0.tokens is p1.tokens):
             return None
+        if not ops.gpt_dual_tokens_ok(p0.tokens):        # the dual kernel is specialised for 2 x 64 fp32 tokens (8 x 8 anchors)
+            return None
         layers = self.model
         src = lambda a, j: a + j if j < 0 else j      # noqa: E731
         base_m = resolve(x[0])
@@ -432,7 +503,9 @@ class Model(nn.Module):
             outs[k] = osum
         return outs
 
-    def _run_layer(self, m, x, x2, cbufs):
+    def _run_layer(self, m, x, x2, cbufs, chain=True):
+        """``chain=False`` (profiling walks): every layer issues its own launches, so the per-layer table charges a Conv's time to the
+        Conv and not to the C3 that would otherwise run it."""
         if m.f == -4:
             return m(x2)
         tgt = self.concat_plan().get(m.i) if cbufs is not None else None
@@ -453,7 +526,7 @@ class Model(nn.Module):
                     return m(x, out=buf[:, off:off + c])
         if cbufs is not None and isinstance(m, Concat) and m.i in cbufs:
             return m(x, out=cbufs[m.i])
-        if (cbufs is not None and not self.training and m.i in self.chain_plan() and self.chain_convs
+        if (chain and cbufs is not None and not self.training and m.i in self.chain_plan() and self.chain_convs
                 and isinstance(x, torch.Tensor) and x.dtype in (torch.bfloat16, torch.float16)):
             return PendingConv(m, x)                 # left to the C3 behind it (one kernel for the conv and the C3's cv1|cv2)
         return m(x)
@@ -473,8 +546,14 @@ class Model(nn.Module):
             layers = layers[:-1]
         lanes = self.stream_lanes() if (self.overlap_streams and x.is_cuda and not profile) else None
         fused = {}                                                    # outputs of a CFT output group still to be handed to their layers
-        fuse_cft = x.is_cuda and self.__dict__.get("fuse_cft_outputs", True)
-        cbufs = {} if (x.is_cuda and self.__dict__.get("plan_concats", True)) else None   # planned concat buffers of this walk
+        fuse_cft = x.is_cuda and self.fuse_cft_outputs and not profile      # profile: one launch group per layer (the reference's per-layer table)
+        cbufs = {} if (x.is_cuda and self.plan_concats) else None   # planned concat buffers of this walk
+        # depth-first prefix (Model.depth_first): {first row: (i0, i1)} and the rows a segment covers
+        seg_at, seg_rows, df = {}, set(), self.depth_first
+        if df and x.is_cuda and not self.training and not profile and cbufs is not None and x.shape[0] >= 2 * int(df[0]) > 0:
+            for sg in self.prefix_segments(df[1] if len(df) > 1 else None):
+                seg_at[sg[0]] = sg
+                seg_rows.update(range(sg[0], sg[1] + 1))
         if lanes is None or 1 not in lanes:
             y, marks = [], []
             if profile:     # reference :252-260,270-271: per-layer time / GFLOPS / params / type.  One stream, HIP events around
@@ -482,6 +561,12 @@ class Model(nn.Module):
                 ops.set_launch_log(flog)
             try:
                 for m in layers:
+                    if m.i in seg_rows:                       # depth-first prefix: the whole segment runs at its first row
+                        if m.i in seg_at:
+                            x = self._run_segment(seg_at[m.i], x2 if m.f == -4 else x, cbufs, int(df[0]))
+                            seg_end = seg_at[m.i][1]
+                        y.append(x if (m.i == seg_end and m.i in self.save) else None)
+                        continue
                     if m.f != -1 and m.f != -4:
                         x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
                     if profile:
@@ -495,7 +580,7 @@ class Model(nn.Module):
                             x = grp.pop(m.i)
                             fused.update(grp)
                         else:
-                            x = self._run_layer(m, x, x2, cbufs)
+                            x = self._run_layer(m, x, x2, cbufs, chain=not profile)
                     if profile:
                         e1.record()
                         marks.append((m, e0, e1, sum(rec[1] for rec in flog[n0:])))
@@ -521,6 +606,14 @@ class Model(nn.Module):
         for i, m in enumerate(layers):
             lane = lanes[i]
             f = m.f
+            if m.i in seg_rows:                               # depth-first prefix: the whole segment runs at its first row, on its lane
+                if m.i in seg_at:
+                    with torch.cuda.stream(streams[lane]):
+                        x = self._run_segment(seg_at[m.i], x2 if f == -4 else x, cbufs, int(df[0]))
+                    seg_end = seg_at[m.i][1]
+                    keep.append(x)
+                y.append(x if (m.i == seg_end and m.i in self.save) else None)
+                continue
             srcs = [] if (f == -4 or i == 0) else ([i - 1] if f == -1 else ([f % i] if isinstance(f, int) else [(i - 1 if j == -1 else j % i) for j in f]))
             if any(lanes[j] != lane for j in srcs):
                 streams[lane].wait_stream(streams[1 - lane])

@@ -205,20 +205,23 @@ def conv2d(x, pk, act, residual=None, out=None, out_dtype=None):
     return out
 
 
-def conv2d_chain_ok_geometry(B, H, W, dtype, pk1, pk2):
-    """``conv2d_chain_ok`` from the input geometry alone ([B, pk1.cin, H, W] of ``dtype`` on the GPU)."""
+def conv2d_chain_ok_geometry(B, H, W, dtype, pk1, pk2, ldx=None, ldy=None):
+    """``conv2d_chain_ok`` from the input geometry alone ([B, pk1.cin, H, W] of ``dtype`` on the GPU).  ``ldx`` / ``ldy``: channels per
+    pixel of the buffers the input / output are slices of (default: dense) - the launcher's 2^31-element limits are on THOSE extents, so
+    'ok' here means the launcher accepts."""
     if dtype not in (torch.bfloat16, torch.float16):
         return False
     if pk2.k != 1 or pk2.s != 1 or pk2.cin != pk1.n or pk2.kpad != pk1.n or pk1.n_valid != pk1.n:
         return False
-    return bool(_lib.load().cft_conv2d_chain_ok(B, H, W, pk1.cin, pk1.n, pk1.kpad, pk1.k, pk1.s, pk2.n, _dt(dtype)))
+    return bool(_lib.load().cft_conv2d_chain_ok(B, H, W, pk1.cin, ldx or pk1.cin, pk1.n, pk1.kpad, pk1.k, pk1.s, pk2.n, ldy or pk2.n, _dt(dtype)))
 
 
 def conv2d_chain_ok(x, pk1, pk2):
     """True when ``conv2d_chain`` takes this pair: conv ``pk1`` (SiLU) then the pointwise conv ``pk2`` on its output (cft_conv2d_chain_ok)."""
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.shape[1] == pk1.cin):
         return False
-    return conv2d_chain_ok_geometry(x.shape[0], x.shape[2], x.shape[3], x.dtype, pk1, pk2)
+    ldx = x.stride(3) if (x.stride(1) == 1 and x.stride(3) >= x.shape[1]) else None      # (another layout is converted to dense NHWC first)
+    return conv2d_chain_ok_geometry(x.shape[0], x.shape[2], x.shape[3], x.dtype, pk1, pk2, ldx=ldx)
 
 
 def conv2d_chain(x, pk1, pk2, act2, out=None):
@@ -500,11 +503,21 @@ def gpt_upsample_add(tokens, s, base, H, W, dtype):
     return out
 
 
+def gpt_dual_tokens_ok(tokens):
+    """What ``cft_gpt_upsample_add2`` hard-codes about its token tensor: [B, 128, C] (two streams x 8 x 8 anchors), fp32, contiguous,
+    C a multiple of 4 and a 16-byte aligned base (it reads rows as float4 at ``b * 128 + s * 64``)."""
+    return (isinstance(tokens, torch.Tensor) and tokens.is_cuda and tokens.dim() == 3 and tokens.shape[1] == 128
+            and tokens.dtype == torch.float32 and tokens.is_contiguous() and tokens.shape[2] % 4 == 0 and tokens.data_ptr() % 16 == 0)
+
+
 def gpt_upsample_add_dual(tokens, base0, base1, H, W, dtype, sum_out=None, want_sum=True):
     """Both streams of a CFT block and the Add behind them in one kernel (cft_gpt_upsample_add2):
     returns (base0 + up(tokens[:, :64]), base1 + up(tokens[:, 64:]), their sum or None); ``sum_out``: write the sum there
     (e.g. a channel slice of a planned concat buffer)."""
     _require_cuda(tokens, "gpt_upsample_add_dual")
+    if not gpt_dual_tokens_ok(tokens):
+        raise ValueError(f"gpt_upsample_add_dual: tokens must be a contiguous, 16-byte aligned fp32 [B, 128, C] tensor (C % 4 == 0), got "
+                         f"{tuple(tokens.shape)} {tokens.dtype} (other anchor grids: gpt_upsample_add per stream)")
     B, T, C = tokens.shape
     base0, ldb0 = as_nhwc(base0)
     base1, ldb1 = as_nhwc(base1)

@@ -131,3 +131,46 @@ def default_init_state_dict(template, seed=0):
     """Like ``seeded_state_dict`` but with the reference constructor's weight distributions (see ``default_init_tensor``):
     the 'freshly built model' regime, where activations shrink through the depth and 16-bit storage errors are small."""
     return {k: (default_init_tensor(k, v, seed).to(v.dtype) if v.is_floating_point() else v.clone()) for k, v in template.items()}
+
+
+def survey_tensor(key, ref, seed=0):
+    """SURVEY.md section 8c / BASELINE.md section 2, literally: the tensors the reference constructor leaves at the identity are
+    randomised - BatchNorm2d ``running_mean ~ N(0, .1)``, ``running_var ~ U(.5, 1.5)``, ``weight ~ U(.5, 1.5)``, ``bias ~ N(0, .1)``,
+    ``GPT.pos_emb ~ N(0, .02)`` - and every other tensor keeps the value the constructor drew (None is returned for those)."""
+    shape = tuple(ref.shape)
+    g = _gen(seed, "survey/" + key)
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "pos_emb":
+        return 0.02 * _randn(shape, g)
+    if ".bn." in key:
+        if leaf == "running_mean":
+            return 0.1 * _randn(shape, g)
+        if leaf in ("running_var", "weight"):
+            return _rand(shape, g, 0.5, 1.5)
+        if leaf == "bias":
+            return 0.1 * _randn(shape, g)
+    return None
+
+
+def survey_state_dict(build, seed=0):
+    """The weights the survey's golden-vector plan prescribes: ``torch.manual_seed(seed)``, build the model with
+    its CONSTRUCTOR (``build()`` -> a reference ``Model`` or this package's - both draw the same values from the global generator,
+    tests/test_host_logic.py pins that), then randomise the BatchNorm statistics / affine parameters and ``pos_emb`` (``survey_tensor``;
+    per-key generators, so reference, oracle and HIP model agree without a checkpoint).  Returns the state dict (CPU, fp32)."""
+    torch.manual_seed(int(seed))
+    model = build()
+    out = {}
+    for k, v in model.state_dict().items():
+        t = survey_tensor(k, v, seed) if v.is_floating_point() else None
+        out[k] = (t.to(v.dtype) if t is not None else v.detach().clone()).cpu()
+    return out
+
+
+def state_dict_fingerprint(sd):
+    """sha256 over (key, shape, bytes) of every tensor, in key order: pins a recipe's weights across machines."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        t = sd[k].detach().cpu().contiguous()
+        h.update(k.encode()); h.update(str(tuple(t.shape)).encode()); h.update(t.reshape(-1).view(torch.uint8).numpy().tobytes() if t.numel() else b"")
+    return h.hexdigest()

@@ -262,9 +262,58 @@ def make_lowp_golden():
     print(f"lowp_ref.pt {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+# name, config name, batch, H, W, fused - the weights SURVEY.md section 8c / BASELINE.md section 2 literally prescribe
+# (utils/seeded.survey_state_dict: torch.manual_seed(0) constructor weights + randomised BatchNorm / pos_emb)
+SURVEY_CASES = [
+    ("survey_l_x3_flir_256", "cfg3", 1, 256, 256, True),
+    ("survey_l_x3_flir_unfused_192", "cfg3", 1, 192, 192, False),
+    ("survey_s_1cft_256", "cfg2", 2, 256, 256, True),
+]
+
+
+def make_survey_golden():
+    """SURVEY.md section 8c's golden-vector plan, literally: ``torch.manual_seed(0)``, the REFERENCE's own
+    ``Model(cfg)`` constructor, BatchNorm statistics / affine and ``pos_emb`` randomised, ``torch.rand``-range inputs; the
+    reference's fp32 forward and its bf16-autocast forward.  tests/golden/survey_ref.pt = {case: raw, raw_bf16, fingerprint of the
+    state dict}: the fingerprint lets the GPU box check that this package's constructor reproduced the reference's weights."""
+    install_reference()
+    sys.path.insert(0, ROOT)
+    import msod_amd  # noqa: F401
+    from msod_amd.models.configs import named_config
+    from msod_amd.utils.seeded import seeded_inputs, state_dict_fingerprint, survey_state_dict
+    from models.yolo_test import Model  # the reference
+    torch.set_num_threads(os.cpu_count())
+    out = {}
+    for name, cfg_name, b, h, w, fused in SURVEY_CASES:
+        cfg = named_config(cfg_name)
+        sd = survey_state_dict(lambda: Model(cfg), seed=0)        # the reference's constructor draws the weights
+        torch.manual_seed(0)
+        model = Model(cfg).eval()
+        model.load_state_dict(sd)
+        if fused:
+            model.fuse()
+        rgb, ir = seeded_inputs(b, h, w, 0)
+        with torch.no_grad():
+            pred, raw = model(rgb, ir)
+            pred, raw = pred.clone(), [r.clone() for r in raw]
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                _, raw16 = model(rgb, ir)
+        flat = lambda rs: torch.cat([r.float().reshape(-1) for r in rs])    # noqa: E731
+        sig = (flat(raw16).sigmoid() - flat(raw).sigmoid()).abs()
+        out[name] = {"case": dict(name=name, cfg=cfg_name, batch=b, height=h, width=w, fused=fused, seed=0),
+                     "raw": raw, "raw_bf16": [r.clone() for r in raw16], "sig_err_bf16": sig.max().item(),
+                     "fingerprint": state_dict_fingerprint(sd), "torch": torch.__version__}
+        print(f"{name:30s} logit std {flat(raw).std().item():.3f}; reference bf16-autocast vs its fp32: {sig.max().item():.3e}; sd {out[name]['fingerprint'][:16]}")
+    path = os.path.join(HERE, "survey_ref.pt")
+    torch.save(out, path)
+    print(f"survey_ref.pt {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "lowp":
         make_lowp_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "survey":
+        make_survey_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "letterbox":
         make_letterbox_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "train":
@@ -280,3 +329,4 @@ if __name__ == "__main__":
         make_train_golden()
         make_letterbox_golden()
         make_lowp_golden()
+        make_survey_golden()

@@ -3,6 +3,8 @@ all-gather the detections; covers equal and ragged shards."""
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -131,3 +133,46 @@ def test_two_rank_ragged_shards():
 def test_two_rank_one_empty_shard():
     """Global batch 1 on 2 ranks: rank 1 has no pair, skips the forward and still joins the collectives."""
     _run(1)
+
+
+# ----------------------------------------------------------------------------- bench.py --gpus N without a launcher (VERDICT r4 item 8)
+def test_launch_command_control_flow():
+    """``bench.py --gpus N`` started as a plain process must become N ranks under torch.distributed.run (or refuse), never time one
+    rank and report it as N: no re-launch at N = 1 or under a launcher, refusal with fewer visible devices, else the torchrun argv."""
+    assert D.launch_command("bench.py", 1, ["--gpus", "1"], env={}) is None
+    assert D.launch_command("bench.py", 4, ["--gpus", "4"], env={"WORLD_SIZE": "4"}, visible_devices=0) is None      # already launched
+    with pytest.raises(SystemExit) as ei:
+        D.launch_command("bench.py", 4, ["--gpus", "4"], env={}, visible_devices=1)
+    assert "only 1 GPU(s) visible" in str(ei.value)
+    cmd = D.launch_command("bench.py", 4, ["--gpus", "4", "--steps", "5"], env={}, visible_devices=8, python="python")
+    assert cmd[:4] == ["python", "-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-5:] == ["bench.py", "--gpus", "4", "--steps", "5"]
+
+
+def test_relaunched_ranks_form_a_process_group(tmp_path):
+    """The argv ``launch_command`` returns, executed for real with two CPU ranks (gloo): the re-launched script sees WORLD_SIZE = 2
+    (so it does not re-launch again), both ranks rendezvous on 127.0.0.1 and an all-gather of their ranks sees {0, 1}."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "relaunch_probe.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "import msod_amd\n"
+        "from msod_amd import distributed as D\n"
+        "cmd = D.launch_command(os.path.abspath(__file__), int(sys.argv[1]), sys.argv[1:], visible_devices=2)\n"
+        "if cmd is not None:\n"
+        "    os.execvp(cmd[0], cmd)\n"
+        "rank, world, local = D.init_from_env(backend='gloo')\n"
+        "seen = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]\n"
+        "dist.all_gather(seen, torch.tensor([rank]))\n"
+        "if rank == 0:\n"
+        "    print('RANKS', world, sorted(int(t) for t in seen), flush=True)\n"
+        "dist.barrier(); dist.destroy_process_group()\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, str(script), "2"], capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "RANKS 2 [0, 1]" in out.stdout, out.stdout + out.stderr[-2000:]

@@ -31,7 +31,7 @@ from test_oracle_golden import load_case
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(__file__)
 GOLDEN = sorted(p for p in glob.glob(os.path.join(HERE, "golden", "*.pt"))
-                if not os.path.basename(p).startswith(("nms_", "ref_ckpt", "s_x3_train", "letterbox_", "lowp_")))
+                if not os.path.basename(p).startswith(("nms_", "ref_ckpt", "s_x3_train", "letterbox_", "lowp_", "survey_")))
 IDS = [os.path.basename(p)[:-3] for p in GOLDEN]
 
 F16_SIGMOID_ATOL = 1e-2     # north_star's 16-bit bound, met in fp16 (measured <= 2e-3)
@@ -237,6 +237,57 @@ def test_reference_constructor_weights_meet_1e2_in_bf16(dev, name):
     assert _rms_rel(raw, rec["raw"]) <= 1.25 * _rms_rel(ref16, rec["raw"]) + 2e-4
 
 
+# ------------------------------------------------------------------------- SURVEY.md section 8c weights, literally
+@pytest.mark.parametrize("name", ["survey_l_x3_flir_256", "survey_l_x3_flir_unfused_192", "survey_s_1cft_256"])
+def test_survey_weights_meet_the_literal_bounds(dev, name):
+    """The golden-vector plan of SURVEY.md section 8c as written: torch.manual_seed(0) CONSTRUCTOR weights, BatchNorm running_mean ~ N(0, .1),
+    running_var / weight ~ U(.5, 1.5), bias ~ N(0, .1), pos_emb ~ N(0, .02) (utils/seeded.survey_state_dict; this package's
+    constructor draws the reference constructor's values - fingerprint pinned in tests/test_oracle_golden.py).  north_star's bounds
+    asserted OUTRIGHT against the reference's recorded fp32 forward: 1e-3 fp32, 1e-2 fp16, **1e-2 bf16** (sigmoid space)."""
+    from test_oracle_golden import survey_case
+    from oracle.cft_oracle import OracleModel
+    rec, cfg, model, sd, rgb, ir = survey_case(name)
+    want_pred, _ = OracleModel(cfg)(model.state_dict(), rgb, ir)
+    pred, raw = _run(model, rgb, ir, dev, torch.float32)
+    _check_fp32(pred, raw, want_pred, rec["raw"])
+    pred, raw = _run(model, rgb, ir, dev, torch.float16)
+    assert _sig_err(raw, rec["raw"]) <= 1e-2
+    pred, raw = _run(model, rgb, ir, dev, torch.bfloat16)
+    assert _sig_err(raw, rec["raw"]) <= 1e-2, f"bf16 sigmoid-space error {_sig_err(raw, rec['raw']):.3e}"
+    assert (pred[..., 4:] - want_pred[..., 4:]).abs().max().item() <= 1e-2
+
+
+def test_cfg3_survey_weights_at_the_benchmarked_batch_of_64_bf16_within_1e2(dev):
+    """The benchmarked configuration (yolov5l + CFTx3, 640x640, 64 pairs, BN folded, HIP-graph replay, bf16) on the weights SURVEY.md
+    section 8c prescribes: pairs 0 and 63 vs the fp32 oracle, **1e-2 asserted outright in bf16** (and in fp16).  The lively
+    `seeded_state_dict` weights of the test below stay as the stress case, gated on the reference's own bf16 level."""
+    from msod_amd.models.configs import named_config
+    from msod_amd.models.yolo_test import Model
+    from msod_amd.utils.seeded import seeded_inputs, survey_state_dict
+    from oracle.cft_oracle import OracleModel
+    cfg = named_config("cfg3")
+    model = Model(cfg)
+    model.load_state_dict(survey_state_dict(lambda: Model(cfg), seed=0))
+    model.fuse()
+    rgb, ir = seeded_inputs(64, 640, 640, 0)
+    idx = [0, 63]
+    want_pred, want_raw = OracleModel(cfg)(model.state_dict(), rgb[idx], ir[idx])
+    model = model.to(dev)
+    x, x2 = rgb.to(dev), ir.to(dev)
+    for dtype in (torch.bfloat16, torch.float16):
+        model.set_compute_dtype(dtype)
+        with torch.no_grad():
+            model.capture(64, 640, 640)
+            pred, raw = model(x, x2)
+            torch.cuda.synchronize()
+            pred, raw = pred[idx].cpu(), [r[idx].cpu() for r in raw]
+        model.release_graphs()
+        assert torch.isfinite(pred).all()
+        err = _sig_err(raw, want_raw)
+        assert err <= 1e-2, f"{dtype}: sigmoid-space error {err:.3e} at the bench shape on the survey weights"
+        assert (pred[..., 4:] - want_pred[..., 4:]).abs().max().item() <= 1e-2
+
+
 def test_cfg3_at_the_benchmarked_batch_of_64(dev):
     """The configuration bench.py times: yolov5l + CFTx3, 640x640, SIXTY-FOUR pairs per GPU, BN folded, HIP-graph replay - at
     this M the dispatcher picks the 256x256 16-wave tiles, the chunk-major K walk and the fused Bottleneck kernels, which
@@ -390,6 +441,35 @@ def test_two_forwards_in_flight_do_not_interfere(dev):
     assert not torch.equal(want[0], want[1])
     for c, w in zip(caps, want):
         assert torch.equal(c.pred, w)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_depth_first_prefix_is_bit_identical(dev, dtype):
+    """Model.depth_first = (chunks, rows): the image-only prefix of each backbone runs sub-batch by sub-batch (Infinity-Cache
+    residency of the P1 / P2 tensors).  Per-image arithmetic is untouched, so outputs are bit-identical to the layer-by-layer walk:
+    even and ragged chunk counts, the whole prefix or its first three rows, one lane or two, eager and HIP-graph replay."""
+    from msod_amd.utils.seeded import seeded_inputs
+    g, cfg, model, _, _ = load_case([p for p in GOLDEN if p.endswith("s_x3_320.pt")][0])
+    model = model.to(dev).set_compute_dtype(dtype)
+    assert model.prefix_segments() == [(0, 4), (5, 9)] and model.prefix_segments(3) == [(0, 2), (5, 7)]
+    rgb, ir = (t.to(dev) for t in seeded_inputs(12, 160, 192, 3))
+    with torch.no_grad():
+        want = model.forward_once(rgb, ir)[0].clone()
+        for df in ((4, None), (5, 3), (6, 5)):
+            model.depth_first = df
+            got = model.forward_once(rgb, ir)[0]
+            assert torch.equal(got, want), df
+        model.overlap_streams = False
+        assert torch.equal(model.forward_once(rgb, ir)[0], want)
+        model.overlap_streams = True
+        model.capture(12, 160, 192)
+        for _ in range(2):
+            got = model(rgb, ir)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        model.depth_first = None                 # the setter drops the graph: the next call walks layer by layer again
+        assert not model._graphs
+    model.release_graphs()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])

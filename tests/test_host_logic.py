@@ -117,7 +117,10 @@ def test_conv2d_chain_eligibility_is_a_host_decision():
     C3s; not the 256 -> 512 pair, yolov5x's 80 / 160-channel layers, fp32, or a padded K.  An ineligible pair is refused by the launcher."""
     lib = _lib.load()
     BF16, F32, F16 = 0, 1, 2
-    ok = lib.cft_conv2d_chain_ok
+    ok_ = lib.cft_conv2d_chain_ok
+
+    def ok(B, H, W, cin, n1, kpad1, k, s_, n2, dt, ldx=None, ldy=None):
+        return ok_(B, H, W, cin, ldx or cin, n1, kpad1, k, s_, n2, ldy or n2, dt)
     assert ok(64, 320, 320, 64, 128, 576, 3, 2, 128, BF16) == 1            # yaml rows 1-2 / 6-7
     assert ok(64, 160, 160, 128, 256, 1152, 3, 2, 256, F16) == 1           # rows 3-4 / 8-9
     assert ok(64, 40, 40, 256, 256, 2304, 3, 1, 256, BF16) == 1            # head C3: cv2[j] + cv1[j+1]
@@ -130,6 +133,11 @@ def test_conv2d_chain_eligibility_is_a_host_decision():
     assert ok(64, 320, 320, 64, 128, 576, 3, 2, 136, BF16) == 0            # second layer wider than the first
     assert ok(64, 320, 320, 64, 128, 576, 3, 2, 100, BF16) == 0            # n2 % 8
     assert ok(0, 320, 320, 64, 128, 576, 3, 2, 128, BF16) == 0 and ok(64, 320, 320, 64, 128, 576, 2, 2, 128, BF16) == 0
+    # 'ok' is the launcher's own validation, incl. its 2^31-element limits on the BUFFER extents (ld, not channel count)
+    assert ok(64, 640, 640, 64, 128, 576, 3, 2, 128, BF16) == 1            # 64 * 640 * 640 * 64 = 1.7e9 elements
+    assert ok(64, 640, 640, 64, 128, 576, 3, 2, 128, BF16, ldx=128) == 0   # the same input as a slice of a 128-channel buffer: 3.4e9
+    assert ok(64, 640, 640, 64, 128, 576, 3, 2, 128, BF16, ldy=1024) == 0  # output slice of a 1024-channel buffer: 6.7e9
+    assert ok(64, 320, 320, 64, 128, 576, 3, 2, 128, BF16, ldy=120) == 0   # ldy must cover the second layer's width
     # null / ineligible arguments are refused before any launch
     st = lib.cft_conv2d_chain(None, None, None, None, None, None, 1, 8, 8, 64, 64, 0, 128, 576, 3, 2, 128, 128, 0, 1, BF16, None)
     assert st == -1 and b"null pointer" in lib.cft_last_error()
