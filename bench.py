@@ -319,6 +319,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2, help="forwards in flight (own graphs, buffers and streams each); 1 = one at a time")
     ap.add_argument("--force-gather", action="store_true", help="N = 1: run the detection all-gather anyway (RCCL with world size 1, OverlappedGather "
                     "inside the timed steps) and report multi_gpu_selfcheck - exercises the N > 1 step mode on the one GPU of a box")
+    ap.add_argument("--no-splitk", action="store_true", help="A/B: the CFT blocks' out_proj / fc2 as one launch each (round 4) instead of split-K + LayerNorm-reduce")
     ap.add_argument("--depth-first", default="", help="CHUNKS[,ROWS]: Model.depth_first - the image-only prefix of each backbone sub-batch by sub-batch "
                     "(Infinity-Cache residency); empty = layer by layer over the whole batch")
     ap.add_argument("--conv-variant", type=int, default=0, help="A/B runs: cft_set_conv_variant() for the whole process (0 = automatic)")
@@ -350,6 +351,7 @@ def main():
     model.plan_concats = not args.no_concat_plan
     model.fuse_cft_outputs = not args.no_cft_fusion
     model.chain_convs = not args.no_conv_chain
+    model.splitk = not args.no_splitk
     if args.depth_first:
         df = [int(v) for v in args.depth_first.split(",")]
         model.depth_first = (df[0], df[1] if len(df) > 1 else None)

@@ -84,6 +84,29 @@ int cft_conv2d_chain(const void* x, const void* w1, const float* bias1, const vo
 int cft_conv2d_chain_ok(int B, int H, int W, int cin, int ldx, int n1, int kpad1, int ksize, int stride, int n2, int ldy, int dtype);
 
 /*
+ * The chained pair with a SHORTCUT on the first layer - inside a C3 with shortcuts (models/common.py:99-109, :138-142) Bottleneck j's 3x3
+ * conv and Bottleneck j+1's 1x1 conv:  y1 = SiLU(conv(x) + b1) + res  (one rounding; the Bottleneck's output AND the next shortcut),
+ * y2 = act2(conv1x1(y1) + b2).  The shortcut tile is DMA-ed into the LDS images, added in fp32 before the rounding, and the images are
+ * stored to y1 while the second GEMM runs: y1 is never re-read from memory and the 1x1 launch disappears.  Bit-identical to
+ * cft_conv2d(x, w1, res=res) followed by cft_conv2d(y1, w2).  n1 == 256 only; otherwise the eligibility of cft_conv2d_chain_ok.
+ * res: dtype, ldr / roff; y1: dtype, ldy1 / yoff1 (may alias res); y2: dtype, ldy2 / yoff2.
+ */
+int cft_conv2d_chain_res(const void* x, const void* w1, const float* bias1, const void* res, void* y1,
+                         const void* w2, const float* bias2, void* y2,
+                         int B, int H, int W, int cin, int ldx, int xoff,
+                         int n1, int kpad1, int ksize, int stride, int ldr, int roff, int ldy1, int yoff1,
+                         int n2, int ldy2, int yoff2, int act2, int dtype, void* stream);
+
+/*
+ * split-K nn.Linear (models/common.py:511 out_proj, :532-538 the MLP's second Linear): parts[s] (float [rows][n], s < splits) =
+ * x[:, s*K/splits : (s+1)*K/splits] . w[:, same]^T (+ bias in s == 0).  For GEMMs with few output tiles and a long K loop: splits x the
+ * workgroups, 1 / splits of the K steps each.  The partial sums are folded into the fp32 residual stream in a FIXED order (reproducible
+ * results) by cft_layernorm_reduce.  cin % K-step == 0, kpad == cin, (kpad / K-step) % splits == 0, 2 <= splits <= 8.
+ */
+int cft_linear_splitk(const void* x, const void* w, const float* bias, float* parts,
+                      int rows, int cin, int ldx, int n, int kpad, int splits, int dtype, void* stream);
+
+/*
  * Bottleneck as one kernel (models/common.py:99-109 with e = 1.0, the form C3 uses :138):
  *   y = (shortcut ? x : 0) + SiLU(conv3x3(SiLU(conv1x1(x) + b1)) + b2),  c -> c -> c channels, 16-bit dtype.
  * x, y: NHWC channel slices (ldx/xoff, ldy/yoff) that must not overlap (the kernel reads a halo of x);
@@ -188,6 +211,10 @@ int cft_gpt_tokenize(const void* rgb, int ld_rgb, int off_rgb, const void* ir, i
  * x float [rows, C] -> y out_dtype [rows, C]. */
 int cft_layernorm(const float* x, const float* gamma, const float* beta, void* y,
                   long rows, int C, float eps, int out_dtype, void* stream);
+/* x (float [rows, C], updated in place) += parts[0] + ... + parts[nparts-1] (float [nparts][rows][C], cft_linear_splitk), then
+ * y = LayerNorm(x): the residual add of models/common.py:543-544 and the LayerNorm of the next sub-block (:529-530, :572) in one pass. */
+int cft_layernorm_reduce(float* x, const float* parts, int nparts, const float* gamma, const float* beta, void* y,
+                         long rows, int C, float eps, int out_dtype, void* stream);
 
 /*
  * Multi-head self-attention core (models/common.py:491-510): for each (b, head)

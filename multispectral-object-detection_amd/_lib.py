@@ -20,7 +20,7 @@ SOURCES = ("runtime.hip", "conv_gemm.hip", "focus_conv.hip", "bottleneck.hip", "
 HEADERS = ("cft_common.h", "conv_common.h")
 
 CFT_BF16, CFT_F32, CFT_F16 = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 
 _c = ctypes
@@ -33,6 +33,9 @@ SIGNATURES = {
     "cft_clock_probe": [_vp, _i, _c.POINTER(_c.c_int), _vp],
     "cft_conv2d_chain": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_conv2d_chain_ok": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
+    "cft_conv2d_chain_res": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_linear_splitk": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cft_layernorm_reduce": [_vp, _vp, _i, _vp, _vp, _vp, _l, _i, _f, _i, _vp],
     "cft_conv2d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_set_conv_variant": [_i],
     "cft_bottleneck": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

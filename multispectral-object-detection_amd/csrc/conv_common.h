@@ -19,6 +19,10 @@ struct ConvParams {
   const unsigned char* w2;   // chained pointwise layer (conv_gemm_kernel CHAIN): packed weights [N2][N], bias, width; y/ldy/yoff/act are ITS output
   const float* bias2;
   int N2;
+  unsigned char* y1;         // CHAIN with a residual (res / ldr / roff): the FIRST layer's output (after + res) is also stored here (ldy1 / yoff1)
+  int ldy1, yoff1;
+  int ksplit, ksteps;        // split-K (pointwise layers on the uniform K walk): workgroup (tile, s) covers K steps [s * ksteps, (s + 1) * ksteps) and
+                             // writes its fp32 partial sums to y + s * M * ldy (bias in split 0 only); ksplit <= 1: the whole K loop
   long x_bytes, w_bytes;   // extent of the input tensor (B*H*W*ldx elements) and of the packed weights (N*Kpad), in bytes
   uint32_t wo_mul, wo_sh, ho_mul, ho_sh;   // exact n / Wo and n / Ho for n < 2^31 as umulhi(n, mul) >> sh (mul == 0: divisor 1)
 };

@@ -44,7 +44,12 @@
 // swizzled [row][64 k] images the staging buffers held; the k-th image = channels 64k..64k+63), the second layer's weights are
 // fetched into the B buffers, and the same fragment reads / MFMAs walk the two images.  Same values, same roundings, same k
 // order as the two launches; the intermediate tensor (M x N elements written, then read) never exists.
-template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0, bool UNIK = false, bool CHAIN = false>
+// CHAIN + residual (p.res, four-image form only): the first layer is a Bottleneck's 3x3 whose output gets the shortcut added BEFORE the
+// one rounding (reference models/common.py:108) and is itself an output (the next shortcut) - the residual tile arrives by LDS-DMA in the
+// image layout, every lane adds "its" dwords in fp32 and writes the rounded sum back in place, and the finished images are stored to y1
+// granule by granule (32 KiB right before each MFMA step of the second GEMM, drained at the barrier behind it).
+// split-K (p.ksplit > 1, pointwise layers on the uniform K walk): see ConvParams.
+template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0, bool UNIK = false, bool CHAIN = false, bool CRES = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvParams p) {
   constexpr int NTHR = 64 * WGM * WGN;
   constexpr int GE = Elem<T>::GE;
@@ -63,7 +68,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
   const int nb = gridDim.x, bid = blockIdx.x;
   const int q = nb >> 3, r = nb & 7, xcd = bid & 7, slot = bid >> 3;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  const int tm = logical / p.tilesN, tn = logical - tm * p.tilesN;
+  int ltile = logical, split = 0;
+  if (p.ksplit > 1) {                    // uniform
+    const int per = nb / p.ksplit;       // host: the grid is tiles * ksplit
+    split = logical / per;
+    ltile = logical - split * per;
+  }
+  const int tm = ltile / p.tilesN, tn = ltile - tm * p.tilesN;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -225,6 +236,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
     }                                                                                                  \
   }
   int u_ci = 0;                                  // scalar: channel offset of the K step inside its tap (tap-major walk)
+  if constexpr (UNIK) {
+    if (p.ksplit > 1) {                          // pointwise layer (host): one tap, the walk starts at this split's first K step
+      const int k0 = split * p.ksteps * BK;
+      u_ci = k0; u_offa = (long)k0 * ES; u_offb = k0 * ES;
+    }
+  }
 
 // The two 32-wide k sub-steps of one staged K step: fragment reads + MFMAs of LDS buffer buf_.
 #define CFT_COMPUTE_STEP(buf_) CFT_COMPUTE_STEP_AT(sA + (buf_) * A_BYTES, sB + (buf_) * B_BYTES)
@@ -255,7 +272,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
   float bias_v[NT];
   if constexpr (!(ABLATE & 32)) conv_load_bias<WN>(p, n0, wn, lane, bias_v);
 
-  const int nk = p.Kpad / BK;
+  const int nk = (UNIK && p.ksplit > 1) ? p.ksteps : p.Kpad / BK;
   if constexpr (UNIK) { CFT_LOAD_TILE_U(0) } else { CFT_LOAD_TILE(0, 0) }
   CFT_STORE_TILE(0)
   __syncthreads();
@@ -290,6 +307,22 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
     const unsigned char* src = (n < p.N2) ? p.w2 + ((long)n * p.N + (k2_) * 64 + g * GE) * ES : zero_page; \
     __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)((dst_) + i * (RPP * 128) + wave * 1024), 16, 0, 0); \
   }
+    constexpr bool with_res = CRES;                             // (its own instantiation: the plain chained kernel keeps its registers)
+    static_assert(!CRES || !W2_RESIDENT, "chained GEMM with a shortcut: four-image form only");
+    if constexpr (!W2_RESIDENT) {
+      if (with_res) {
+        // the shortcut tile -> the image area, in the image layout (row r, slot s holds channel granule s ^ (r & 7) of image k): the staging
+        // pattern of the K loop; rows beyond M read the zero page
+#pragma unroll
+        for (int k2 = 0; k2 < NK2; ++k2)
+#pragma unroll
+          for (int i = 0; i < A_PER; ++i) {
+            const int m = m0 + r0 + i * RPP;
+            const unsigned char* src = (m < p.M) ? p.res + ((long)m * p.ldr + p.roff + k2 * 64 + g * GE) * ES : zero_page;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sA + k2 * A_BYTES + i * (RPP * 128) + wave * 1024), 16, 0, 0);
+          }
+      }
+    }
     if constexpr (W2_RESIDENT) {
 #pragma unroll
       for (int k2 = 0; k2 < NK2; ++k2) CFT_LOAD_W2(k2, sB2 + k2 * B_BYTES)
@@ -305,6 +338,36 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
     // First layer's bias + SiLU + rounding on the accumulators; lanes l / l^1 hold neighbouring channels of the same four pixels:
     // they swap half of their values (one DPP move) so that each writes two packed channel PAIRS (even lane: pixels 0,1; odd: 2,3).
     const bool odd = lane & 1;
+    if (with_res) {
+      __syncthreads();                                     // the shortcut tile (and W2 step 0) landed, visible to every wave
+      // lanes l / l^1 exchange fp32 values (two DPP moves) so that each owns the channel PAIR (c, c + 1) of two pixels; it reads the shortcut's
+      // dword for each, adds in fp32 - act(acc + bias) + shortcut, the operation order of the plain epilogue - rounds once and writes the dword back
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = apply_act<CFT_ACT_SILU>(acc[i][j][e] + bias_v[j]);
+          const float ga = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(odd ? v[0] : v[2]), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+          const float gb = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(odd ? v[1] : v[3]), 0xB1, 0xF, 0xF, true));
+          float lo0 = odd ? ga : v[0], hi0 = odd ? v[2] : ga;      // pixel A: channels c, c + 1
+          float lo1 = odd ? gb : v[1], hi1 = odd ? v[3] : gb;      // pixel B = A + 1
+          const int row = wm * WM + i * 16 + lgrp * 4 + (odd ? 2 : 0);
+          const int col = wn * WN + j * 16 + (lrow & 14);
+          const int c = col & 63;
+          unsigned char* img = sA + (col >> 6) * A_BYTES + (c & 7) * 2;
+          uint32_t* pa = reinterpret_cast<uint32_t*>(img + row * 128 + (((c >> 3) ^ (row & 7)) << 4));
+          uint32_t* pb = reinterpret_cast<uint32_t*>(img + (row + 1) * 128 + (((c >> 3) ^ ((row + 1) & 7)) << 4));
+          float r0l, r0h, r1l, r1h;
+          Elem<TH>::unpack2(*pa, r0l, r0h);
+          Elem<TH>::unpack2(*pb, r1l, r1h);
+          lo0 += r0l; hi0 += r0h; lo1 += r1l; hi1 += r1h;
+          *pa = Elem<TH>::pack2(lo0, hi0);
+          *pb = Elem<TH>::pack2(lo1, hi1);
+          acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -324,6 +387,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
         *reinterpret_cast<uint32_t*>(img + (row + 1) * 128 + (((c >> 3) ^ ((row + 1) & 7)) << 4)) = d1;
         acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
+    }
     if constexpr (W2_RESIDENT) {
       __syncthreads();
 #pragma unroll
@@ -332,18 +396,34 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
       // Four images I0..I3, one extra buffer X.  An image is dead once its K step is done, so the later weight steps land in dead
       // images: only the second step's weights are waited for with nothing to do (X and I0 are both free only after step 0).
       static_assert(NK2 == 4 && B_BYTES <= A_BYTES, "chained GEMM: streamed second-layer weights are scheduled for four K steps");
+// residual form: image k2_ IS a quarter of the first layer's output tile (final values) - store it to y1 as 16-byte granules (thread (r0, slot)
+// holds granule slot ^ (row & 7) of its rows: eight consecutive threads write one full 128-byte line).  Issued right before an MFMA step; the
+// barrier behind that step drains the stores, so an image is never overwritten (by a later W2 step) before it is in flight to memory.
+#define CFT_STORE_IMAGE(k2_)                                                                           \
+      if (with_res) {                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < A_PER; ++i) {                                            \
+          const int row = r0 + i * RPP, m = m0 + row;                                                  \
+          const gran_t t_ = *reinterpret_cast<const gran_t*>(sA + (k2_) * A_BYTES + row * 128 + (slot_s << 4)); \
+          if (m < p.M) *reinterpret_cast<gran_t*>(p.y1 + ((long)m * p.ldy1 + p.yoff1 + (k2_) * 64 + g * GE) * ES) = t_; \
+        }                                                                                              \
+      }
       __syncthreads();                                     // images written, W2 step 0 in X
+      CFT_STORE_IMAGE(0)
       CFT_COMPUTE_STEP_AT(sA, sB2)
-      __syncthreads();                                     // X and I0 are free
+      __syncthreads();                                     // X and I0 are free (I0 is on its way to y1)
       CFT_LOAD_W2(1, sB2)
       CFT_LOAD_W2(2, sA)
+      CFT_STORE_IMAGE(1)
       __syncthreads();                                     // both landed
       CFT_COMPUTE_STEP_AT(sA + A_BYTES, sB2)
       __syncthreads();                                     // I1 is free
       CFT_LOAD_W2(3, sA + A_BYTES)                         // lands under step 2
+      CFT_STORE_IMAGE(2)
       CFT_COMPUTE_STEP_AT(sA + 2 * A_BYTES, sA)
       __syncthreads();
+      CFT_STORE_IMAGE(3)
       CFT_COMPUTE_STEP_AT(sA + 3 * A_BYTES, sA + A_BYTES)
+#undef CFT_STORE_IMAGE
     }
 #undef CFT_LOAD_W2
     __syncthreads();
@@ -361,6 +441,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_gemm_kernel(const ConvPar
     return;
   }
   if constexpr (ABLATE & 32) conv_load_bias<WN>(p, n0, wn, lane, bias_v);   // A/B probe: the round-1 placement
+  if (p.ksplit > 1) {                    // uniform: fp32 partial sums of this split (host: out_f32, no activation, no residual)
+    ConvParams ps = p;
+    ps.y = p.y + (long)split * p.M * p.ldy * 4;
+    if (split != 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bias_v[j] = 0.0f;
+    }
+    conv_epilogue_impl<typename Half16<T>::type, WM, WN, CFT_ACT_NONE, true>(ps, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
+    return;
+  }
   conv_epilogue<typename Half16<T>::type, WM, WN>(p, acc, smem, m0, n0, wm, wn, wave, lane, bias_v);
 }
 
@@ -385,16 +475,17 @@ extern "C" int cft_set_conv_variant(int v) {
   return old;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0, bool UNIK = false, bool CHAIN = false>
+template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0, bool UNIK = false, bool CHAIN = false, bool CRES = false>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
   // (chained kernel with four 64-channel images: they take all of the staging area, the second layer's weights one buffer behind it)
   constexpr int smem_bytes = (CHAIN && BN / 64 > 2) ? (BN / 64) * BM * 128 + BN * 128 : 2 * (BM + BN) * 128;
   static_assert(!CHAIN || (BN / 64) * BM * 128 >= 2 * (BM + BN) * 128 || BN / 64 <= 2, "chained GEMM: LDS map");
-  cft_allow_lds<&conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE, UNIK, CHAIN>>(smem_bytes);
+  cft_allow_lds<&conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE, UNIK, CHAIN, CRES>>(smem_bytes);
   ConvParams q = p;
   const int tilesM = (p.M + BM - 1) / BM;
   q.tilesN = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE, UNIK, CHAIN>), dim3(tilesM * q.tilesN), dim3(64 * WGM * WGN), smem_bytes, stream, q);
+  if (!UNIK || q.ksplit < 1) q.ksplit = 1;     // (split-K exists on the uniform K walk only; cft_linear_splitk checks eligibility first)
+  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE, UNIK, CHAIN, CRES>), dim3(tilesM * q.tilesN * q.ksplit), dim3(64 * WGM * WGN), smem_bytes, stream, q);
   return cft_check_launch("conv_gemm_kernel");
 }
 
@@ -467,7 +558,7 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   //    (256x256 for wide layers, 512x128 for 128-channel layers) reach 0.9-1.1 PFLOP/s on K >= 1152;
   //  * HBM-bound layers (1x1, K <= 256) run best on 8-wave 128x128 / 256x64 tiles (4.3-4.8 TB/s);
   //  * a tile configuration is only used if it yields at least one workgroup per CU.
-  auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * (p.ksplit > 1 ? p.ksplit : 1); };   // workgroups
   const long kCUs = 192;   // accept a configuration once it yields >= 0.75 workgroups per CU (256 CUs)
   if (p.N <= 64) {
     if (tiles(256, 64) >= kCUs) return launch_auto<T, 256, 64, 4, 2>(p, stream);
@@ -535,6 +626,7 @@ static int fill_conv_params(ConvParams& p, const void* x, const void* w, const f
   p.act = act; p.out_f32 = out_dtype == CFT_F32; p.res_f32 = res_dtype == CFT_F32;
   p.M = (int)M; p.tilesN = 0;
   p.w2 = nullptr; p.bias2 = nullptr; p.N2 = 0;
+  p.y1 = nullptr; p.ldy1 = 0; p.yoff1 = 0; p.ksplit = 1; p.ksteps = 0;
   p.x_bytes = (long)B * H * W * ldx * cft_elem_size(dtype);
   p.w_bytes = (long)n * kpad * cft_elem_size(dtype);
   set_magic(Wo, p.wo_mul, p.wo_sh);
@@ -568,6 +660,7 @@ template <typename T>
 static int dispatch_chain(const ConvParams& p, hipStream_t stream) {
   if constexpr (sizeof(T) == 2) {
     if (p.N == 128) return launch_conv<T, 192, 128, 2, 4, true, 0, true, true>(p, stream);   // two workgroups per CU (80 KiB)
+    if (p.y1 != nullptr) return launch_conv<T, 256, 256, 4, 4, true, 0, true, true, true>(p, stream);   // + shortcut (cft_conv2d_chain_res)
     return launch_conv<T, 256, 256, 4, 4, true, 0, true, true>(p, stream);                   // 16 waves, all 160 KiB
   } else return CFT_EINVAL;
 }
@@ -586,6 +679,55 @@ extern "C" int cft_conv2d_chain(const void* x, const void* w1, const float* bias
   p.w2 = (const unsigned char*)w2; p.bias2 = bias2; p.N2 = n2;
   CFT_DISPATCH_DTYPE(dtype, T, return dispatch_chain<T>(p, as_stream(stream)));
   return CFT_EINVAL;
+}
+
+// The chained pair with a shortcut on the FIRST layer (a Bottleneck's 3x3, reference models/common.py:108: x + cv2(cv1(x))) whose sum is
+// also the next shortcut: y1 = SiLU(conv(x) + b1) + res (one rounding), y2 = act2(conv1x1(y1) + b2).  256-channel first layers only (the
+// four-image form of the chained kernel); y1 may alias res.
+extern "C" int cft_conv2d_chain_res(const void* x, const void* w1, const float* bias1, const void* res, void* y1,
+                                    const void* w2, const float* bias2, void* y2,
+                                    int B, int H, int W, int cin, int ldx, int xoff,
+                                    int n1, int kpad1, int ksize, int stride, int ldr, int roff, int ldy1, int yoff1,
+                                    int n2, int ldy2, int yoff2, int act2, int dtype, void* stream) {
+  CFT_REQUIRE(w2 != nullptr && res != nullptr && y1 != nullptr, "cft_conv2d_chain_res: null pointer");
+  ConvParams p;
+  const int rc = fill_conv_params(p, x, w1, bias1, res, y2, B, H, W, cin, ldx, xoff, n1, kpad1, ksize, stride,
+                                  ldy2, yoff2, ldr, roff, act2, dtype, dtype, dtype);
+  if (rc != CFT_OK) return rc;
+  CFT_REQUIRE(n2 % 8 == 0 && n2 > 0 && ldy2 >= yoff2 + n2, "cft_conv2d_chain_res: n2 must be a positive multiple of 8 and fit ldy2");
+  CFT_REQUIRE(chain_ok(p, n2, dtype) && n1 == 256, "cft_conv2d_chain_res: layer pair not eligible (256-channel first layer, see cft_conv2d_chain_ok)");
+  CFT_REQUIRE(ldy1 % 8 == 0 && yoff1 % 8 == 0 && ldy1 >= yoff1 + n1 && ldr >= roff + n1, "cft_conv2d_chain_res: y1 / res ld and offset must be multiples of 8 and cover n1 channels");
+  CFT_REQUIRE((long)p.M * ldy1 < (1L << 31) && (long)p.M * ldr < (1L << 31), "cft_conv2d_chain_res: tensor exceeds 2^31 elements (split the batch)");
+  p.w2 = (const unsigned char*)w2; p.bias2 = bias2; p.N2 = n2;
+  p.y1 = (unsigned char*)y1; p.ldy1 = ldy1; p.yoff1 = yoff1;
+  CFT_DISPATCH_DTYPE(dtype, T, return dispatch_chain<T>(p, as_stream(stream)));
+  return CFT_EINVAL;
+}
+
+// split-K form of a pointwise layer / nn.Linear: parts[s] (fp32, [rows][n], s < splits) = x[:, s*K/splits : (s+1)*K/splits] . w^T (+ bias
+// in s = 0).  For GEMMs with few output tiles and a long K loop (the CFT block's out_proj / fc2 at 8192 rows: reference
+// models/common.py:511, :532-538): splits x the workgroups, each with 1 / splits of the K steps.  The partial sums are added to the fp32
+// residual stream - in a FIXED order, so results are reproducible - by the LayerNorm that reads it next (cft_layernorm_reduce).
+extern "C" int cft_linear_splitk(const void* x, const void* w, const float* bias, float* parts,
+                                 int rows, int cin, int ldx, int n, int kpad, int splits, int dtype, void* stream) {
+  CFT_REQUIRE(parts != nullptr, "cft_linear_splitk: null pointer");
+  CFT_REQUIRE(splits >= 2 && splits <= 8, "cft_linear_splitk: 2 <= splits <= 8");
+  ConvParams p;
+  const int rc = fill_conv_params(p, x, w, bias, nullptr, parts, 1, 1, rows, cin, ldx, 0, n, kpad, 1, 1,
+                                  n, 0, 0, 0, CFT_ACT_NONE, dtype, CFT_F32, dtype);
+  if (rc != CFT_OK) return rc;
+  const int bk = 8 * cft_granule(dtype);
+  CFT_REQUIRE(cin % bk == 0 && kpad == cin && 2L * kpad * cft_elem_size(dtype) + 128 <= CFT_ZERO_REGION_BYTES,
+              "cft_linear_splitk: needs the uniform K walk (cin a multiple of the K step, no K padding)");
+  CFT_REQUIRE((kpad / bk) % splits == 0, "cft_linear_splitk: the K steps must divide evenly among the splits");
+  CFT_REQUIRE((long)splits * rows * n < (1L << 31), "cft_linear_splitk: partial-sum buffer exceeds 2^31 elements");
+  p.ksplit = splits; p.ksteps = kpad / bk / splits;
+  const int saved = g_conv_variant;
+  if (saved == 900 || saved == 1) g_conv_variant = 0;   // (variants 900 / 1 force the generic address path: split-K lives on the uniform walk)
+  int st = CFT_EINVAL;
+  CFT_DISPATCH_DTYPE(dtype, T, st = dispatch_conv<T>(p, as_stream(stream)));
+  g_conv_variant = saved;
+  return st;
 }
 
 // 1 if cft_conv2d_chain takes this pair of layers (first layer: its cft_conv2d geometry, SiLU; second: pointwise, n2 outputs; ldx / ldy: channels

@@ -457,6 +457,89 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   }
 }
 
+// LayerNorm that first folds split-K partial sums into the residual stream: x[row] += parts[0][row] + parts[1][row] + ... (fixed order;
+// x is written back), then y = LayerNorm(x).  One wave per row, the row lives in registers between the two steps.
+template <int MAXV>
+__global__ void __launch_bounds__(256) layernorm_reduce_kernel(float* __restrict__ x, const float* __restrict__ parts, int nparts, long part_stride,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               unsigned char* __restrict__ y, long rows, int C, float eps, int out_dtype) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = C >> 2;
+  float4* xr = reinterpret_cast<float4*>(x + row * C);
+  float4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int idx = lane + k * 64;
+    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < nv) {
+      float4 a = xr[idx];
+      for (int sp = 0; sp < nparts; ++sp) {
+        const float4 q = reinterpret_cast<const float4*>(parts + sp * part_stride + row * C)[idx];
+        a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+      }
+      xr[idx] = a;
+      v[k] = a;
+    }
+    s += v[k].x + v[k].y + v[k].z + v[k].w;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int idx = lane + k * 64;
+    if (idx < nv) {
+      const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+      q += a * a + b * b + c * c + d * d;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int idx = lane + k * 64;
+    if (idx < nv) {
+      const float4 gm = reinterpret_cast<const float4*>(gamma)[idx];
+      const float4 bt = reinterpret_cast<const float4*>(beta)[idx];
+      float o[4] = {(v[k].x - mean) * rstd * gm.x + bt.x, (v[k].y - mean) * rstd * gm.y + bt.y,
+                    (v[k].z - mean) * rstd * gm.z + bt.z, (v[k].w - mean) * rstd * gm.w + bt.w};
+      if (out_dtype == CFT_F32) {
+        *reinterpret_cast<float4*>(y + (row * C + idx * 4L) * 4) = *reinterpret_cast<float4*>(o);
+      } else {
+        uint2 pk;
+        if (out_dtype == CFT_BF16) { pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]); }
+        else { pk.x = pack_f16x2(o[0], o[1]); pk.y = pack_f16x2(o[2], o[3]); }
+        *reinterpret_cast<uint2*>(y + (row * C + idx * 4L) * 2) = pk;
+      }
+    }
+  }
+}
+
+// x (fp32 [rows][C], updated in place) += parts[0 .. nparts) (fp32 [nparts][rows][C], e.g. from cft_linear_splitk); y = LayerNorm(x).
+extern "C" int cft_layernorm_reduce(float* x, const float* parts, int nparts, const float* gamma, const float* beta, void* y,
+                                    long rows, int C, float eps, int out_dtype, void* stream) {
+  CFT_REQUIRE(x && parts && gamma && beta && y, "cft_layernorm_reduce: null pointer");
+  CFT_REQUIRE(nparts >= 1 && nparts <= 8, "cft_layernorm_reduce: 1 <= nparts <= 8");
+  CFT_REQUIRE(C % 4 == 0 && C >= 4 && C <= 4096, "cft_layernorm_reduce: C must be a multiple of 4 and <= 4096");
+  CFT_REQUIRE(cft_is_dtype(out_dtype), "cft_layernorm_reduce: bad out dtype");
+  CFT_REQUIRE(rows > 0, "cft_layernorm_reduce: rows must be positive");
+  const int nv = C >> 2;
+  const long grid = (rows + 3) / 4;
+  const long ps = rows * (long)C;
+  if (nv <= 64 * 2)
+    hipLaunchKernelGGL(layernorm_reduce_kernel<2>, dim3(grid), dim3(256), 0, as_stream(stream), x, parts, nparts, ps, gamma, beta, (unsigned char*)y, rows, C, eps, out_dtype);
+  else if (nv <= 64 * 5)
+    hipLaunchKernelGGL(layernorm_reduce_kernel<5>, dim3(grid), dim3(256), 0, as_stream(stream), x, parts, nparts, ps, gamma, beta, (unsigned char*)y, rows, C, eps, out_dtype);
+  else
+    hipLaunchKernelGGL(layernorm_reduce_kernel<16>, dim3(grid), dim3(256), 0, as_stream(stream), x, parts, nparts, ps, gamma, beta, (unsigned char*)y, rows, C, eps, out_dtype);
+  return cft_check_launch("layernorm_reduce_kernel");
+}
+
 extern "C" int cft_layernorm(const float* x, const float* gamma, const float* beta, void* y,
                              long rows, int C, float eps, int out_dtype, void* stream) {
   CFT_REQUIRE(x && gamma && beta && y, "cft_layernorm: null pointer");

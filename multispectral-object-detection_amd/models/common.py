@@ -267,6 +267,15 @@ class C3(_Packed):
         head = cat[:, :c_]
         y = head
         n = len(self.m)
+        if self.chain and n >= 2 and not self.training and self._res_chainable(head):
+            # WITH shortcuts (backbone C3s, 256 channels): Bottleneck j's output is the next shortcut AND the input of Bottleneck j + 1's 1x1 -
+            # cv2[j] (+ shortcut) and cv1[j + 1] run as one launch (ops.conv2d_chain_res): n + 1 launches instead of 2 n, no re-read of y
+            h = self.m[0].cv1(y)
+            for j in range(n - 1):
+                blk, nxt = self.m[j], self.m[j + 1]
+                y, h = ops.conv2d_chain_res(h, blk.cv2._packed(h.dtype, h.device), y, nxt.cv1._packed(h.dtype, h.device), _act_code(nxt.cv1.act))
+            self.m[n - 1].cv2(h, residual=y, out=head)
+            return self.cv3(cat, out=out)
         # Without shortcuts a Bottleneck's output has ONE reader, the next Bottleneck's 1x1 (reference models/common.py:108-109, :142):
         # cv2[j] + cv1[j + 1] then run as one launch (ops.conv2d_chain) and the tensor between the two Bottlenecks never exists.
         can = [self.chain and j + 1 < n and self._chainable(self.m[j], self.m[j + 1], head) for j in range(n)]
@@ -285,6 +294,20 @@ class C3(_Packed):
         return self.cv3(cat, out=out)
 
     chain = True                   # Model.chain_convs switches it (A/B)
+
+    def _res_chainable(self, y):
+        """Every Bottleneck has a shortcut and (cv2[j], cv1[j + 1]) is a pair ``ops.conv2d_chain_res`` takes on tensors shaped like ``y``."""
+        if not (isinstance(y, torch.Tensor) and y.is_cuda and y.dtype in (torch.bfloat16, torch.float16)):
+            return False
+        for j, blk in enumerate(self.m):
+            if not blk.add or _act_code(blk.cv1.act) != ACT_SILU or _act_code(blk.cv2.act) != ACT_SILU:
+                return False
+            pk1, pk2 = blk.cv1._packed(y.dtype, y.device), blk.cv2._packed(y.dtype, y.device)
+            if ops.bottleneck_fusable(y, pk1, pk2, ACT_SILU, ACT_SILU):
+                return False               # 64 / 128 channels: the patch-resident Bottleneck kernel
+            if j + 1 < len(self.m) and not ops.conv2d_chain_res_ok(y, pk2, self.m[j + 1].cv1._packed(y.dtype, y.device)):
+                return False
+        return True
 
     def _chainable(self, blk, nxt, y):
         """``blk.cv2`` (3x3) and ``nxt.cv1`` (1x1) can run as one kernel on tensors shaped like ``y``: inference, no shortcut on either
@@ -467,8 +490,10 @@ class SelfAttention(_Packed):
         out.flops_per_row = 2.0 * d * h * dk
         return qkv, out, dkp
 
-    def forward(self, x, attention_mask=None, attention_weights=None, residual=None):
-        """x: [B*128, d] in the compute dtype.  Returns out_proj(attn) (+ residual, fp32)."""
+    def forward(self, x, attention_mask=None, attention_weights=None, residual=None, splitk=False):
+        """x: [B*128, d] in the compute dtype.  Returns out_proj(attn) (+ residual, fp32, in place).  ``splitk`` (the transformer block's
+        inference path): returns the out_proj's fp32 split-K partial sums [s, rows, d] when ``ops.splitk_choice`` splits it (``residual`` is
+        then NOT updated - ``ops.layernorm_reduce`` does that), else None after the in-place update."""
         if attention_mask is not None or attention_weights is not None:
             raise NotImplementedError("attention_mask / attention_weights are unused by GPT (reference :497-500)")
         qkv_w, out_w, dkp = self._packed(x.dtype, x.device)
@@ -479,8 +504,13 @@ class SelfAttention(_Packed):
             proj = ops.linear(att, out_w, out_dtype=torch.float32)          # resid_drop(out_proj(.)) then the residual add
             ops.dropout_(proj, self.resid_drop.p)
             return ops.add_rows_(residual, proj)
-        return ops.linear(att, out_w, residual=residual, out=residual,
-                          out_dtype=torch.float32 if residual is not None else None)
+        if splitk and residual is not None and not self.training:
+            s_ = ops.splitk_choice(att.shape[0], out_w, att.dtype)
+            if s_ > 1:
+                return ops.linear_splitk(att, out_w, s_)         # fp32 partial sums; the caller's next LayerNorm folds them into ``residual``
+        out = ops.linear(att, out_w, residual=residual, out=residual,
+                         out_dtype=torch.float32 if residual is not None else None)
+        return None if splitk else out
 
 
 class myTransformerBlock(_Packed):
@@ -505,19 +535,39 @@ class myTransformerBlock(_Packed):
         ln = [_f32(t, device) for t in (self.ln_input.weight, self.ln_input.bias, self.ln_output.weight, self.ln_output.bias)]
         return fc1, fc2, ln
 
-    def forward(self, x, compute_dtype=torch.bfloat16):
+    splitk = True        # inference: out_proj / fc2 as split-K GEMMs where ops.splitk_choice splits them (GPT.splitk switches all blocks; A/B)
+
+    def forward(self, x, compute_dtype=torch.bfloat16, pending=None):
+        """``pending``: fp32 split-K partial sums of the PREVIOUS block's fc2 that are not yet folded into ``x`` (or None).  Returns this
+        block's own pending partial sums (or None when its fc2 updated ``x`` in place); ``GPT.forward`` hands them to the next block /
+        ``ln_f``.  Each LayerNorm that follows a split GEMM is ``ops.layernorm_reduce``: x += partial sums (fixed order), then LayerNorm."""
         fc1, fc2, ln = self._packed(compute_dtype, x.device)
-        y = ops.layernorm(x, ln[0], ln[1], compute_dtype, self.ln_input.eps)
-        self.sa(y, residual=x)                                   # x += out_proj(attention(LN(x)))
-        y = ops.layernorm(x, ln[2], ln[3], compute_dtype, self.ln_output.eps)
+        split = self.splitk and not self.training and x.is_cuda
+
+        def norm(parts, g, b, eps):
+            if parts is not None:
+                return ops.layernorm_reduce(x, parts, g, b, compute_dtype, eps)
+            return ops.layernorm(x, g, b, compute_dtype, eps)
+        y = norm(pending, ln[0], ln[1], self.ln_input.eps)
+        parts = None
+        if split:
+            parts = self.sa(y, residual=x, splitk=True)           # x += out_proj(attention(LN(x))), or its partial sums
+        else:
+            self.sa(y, residual=x)
+        y = norm(parts, ln[2], ln[3], self.ln_output.eps)
         hid = ops.linear(y, fc1, act=ACT_GELU)
         pd = self.mlp[3].p if (self.training and len(self.mlp) > 3) else 0.0
         if pd > 0:
             z = ops.linear(hid, fc2, out_dtype=torch.float32)
             ops.dropout_(z, pd)
-            return ops.add_rows_(x, z)
+            ops.add_rows_(x, z)
+            return None
+        if split:
+            s_ = ops.splitk_choice(hid.shape[0], fc2, hid.dtype)
+            if s_ > 1:
+                return ops.linear_splitk(hid, fc2, s_)                     # folded into x by the next LayerNorm (next block's ln_input / ln_f)
         ops.linear(hid, fc2, residual=x, out=x, out_dtype=torch.float32)  # x += fc2(gelu(fc1(LN(x))))
-        return x
+        return None
 
 
 class GPT(_Packed):
@@ -566,9 +616,13 @@ class GPT(_Packed):
         if self.training:
             ops.dropout_(tok, self.drop.p)                       # self.drop(pos_emb + token_embeddings), reference :611
         t2 = tok.view(B * 128, C)
+        pending = None                                           # split-K partial sums of the last fc2, not yet folded into t2
         for blk in self.trans_blocks:
-            blk(t2, dtype)
-        tok_f = ops.layernorm(t2, lnf_w, lnf_b, torch.float32, self.ln_f.eps).view(B, 128, C)
+            pending = blk(t2, dtype, pending)
+        if pending is not None:
+            tok_f = ops.layernorm_reduce(t2, pending, lnf_w, lnf_b, torch.float32, self.ln_f.eps).view(B, 128, C)
+        else:
+            tok_f = ops.layernorm(t2, lnf_w, lnf_b, torch.float32, self.ln_f.eps).view(B, 128, C)
         return PendingBilinear(tok_f, 0, H, W, dtype), PendingBilinear(tok_f, 1, H, W, dtype)
 
 

@@ -417,6 +417,22 @@ class Model(nn.Module):
             layers[i1](x, out=full[b0:b1])
         return full
 
+    @property
+    def splitk(self):
+        """Run the CFT blocks' out_proj / fc2 GEMMs as split-K launches where ``ops.splitk_choice`` splits them (default; the LayerNorm that
+        follows folds the fp32 partial sums into the residual stream in a fixed order).  ``False``: one launch per GEMM with the residual
+        add in its epilogue (A/B; results differ by fp32 summation order only)."""
+        return self.__dict__.get("_splitk", True)
+
+    @splitk.setter
+    def splitk(self, on):
+        from .common import myTransformerBlock
+        self.__dict__["_splitk"] = bool(on)
+        for m in self.modules():
+            if isinstance(m, myTransformerBlock):
+                m.splitk = bool(on)
+        self.__dict__.get("_graphs", {}).clear()
+
     def chain_plan(self):
         """Indices of the ``Conv`` layers whose output is read by exactly one layer, the ``C3`` right behind them (``f == -1``): yaml
         rows 1, 3, 6, 8, 13, 15 of the x3 configs (the convs in front of SPP or Concat do not qualify).  Such a conv is handed to its

@@ -253,6 +253,45 @@ def conv2d_chain(x, pk1, pk2, act2, out=None):
     return out
 
 
+def conv2d_chain_res_ok(x, pk1, pk2):
+    """True when ``conv2d_chain_res`` takes the pair: ``conv2d_chain_ok`` and a 256-channel first layer (the four-image form of the kernel)."""
+    return pk1.n == 256 and conv2d_chain_ok(x, pk1, pk2)
+
+
+def conv2d_chain_res(x, pk1, res, pk2, act2, out1=None, out2=None):
+    """(y1, y2) = (SiLU(conv(x)) + res, act2(conv1x1(y1))) as ONE kernel (cft_conv2d_chain_res): Bottleneck j's 3x3 conv with its shortcut
+    and Bottleneck j+1's 1x1 conv inside a C3 with shortcuts.  Bit-identical to ``conv2d(x, pk1, SILU, residual=res)`` followed by
+    ``conv2d(y1, pk2, act2)``; y1 is stored but never re-read, and the 1x1 launch disappears."""
+    _require_cuda(x, "conv2d_chain_res")
+    if not conv2d_chain_res_ok(x, pk1, pk2):
+        raise ValueError("conv2d_chain_res: layer pair not eligible (conv2d_chain_res_ok)")
+    x, ldx = as_nhwc(x)
+    B, C, H, W = x.shape
+    p = pk1.k // 2
+    Ho, Wo = (H + 2 * p - pk1.k) // pk1.s + 1, (W + 2 * p - pk1.k) // pk1.s + 1
+    if tuple(res.shape) != (B, pk1.n, Ho, Wo) or res.dtype != x.dtype:
+        raise ValueError(f"conv2d_chain_res: residual has shape {tuple(res.shape)}, expected {(B, pk1.n, Ho, Wo)}")
+    ldr = _view_ld(res, "conv2d_chain_res residual")
+    if out1 is None:
+        out1 = new_nhwc(B, Ho, Wo, pk1.n, x.dtype, x.device)
+    if out2 is None:
+        out2 = new_nhwc(B, Ho, Wo, pk2.n, x.dtype, x.device)
+    if tuple(out1.shape) != (B, pk1.n, Ho, Wo) or tuple(out2.shape) != (B, pk2.n, Ho, Wo) or out1.dtype != x.dtype or out2.dtype != x.dtype:
+        raise ValueError("conv2d_chain_res: output shape / dtype mismatch")
+    ldy1, ldy2 = _view_ld(out1, "conv2d_chain_res out1"), _view_ld(out2, "conv2d_chain_res out2")
+    lib = _lib.load()
+    es = x.element_size()
+    M = B * Ho * Wo
+    abytes = (B * H * W * pk1.cin + 2 * M * pk1.n_valid + M * pk2.n_valid + pk1.w.numel() + pk2.w.numel()) * es
+    args = (x.data_ptr(), pk1.w.data_ptr(), pk1.bias.data_ptr() if pk1.bias is not None else None, res.data_ptr(), out1.data_ptr(),
+            pk2.w.data_ptr(), pk2.bias.data_ptr() if pk2.bias is not None else None, out2.data_ptr(),
+            B, H, W, pk1.cin, ldx, 0, pk1.n, pk1.kpad, pk1.k, pk1.s, ldr, 0, ldy1, 0, pk2.n, ldy2, 0, act2, _dt(x.dtype), _stream())
+    st = _timed(f"conv_chainres_k{pk1.k}s{pk1.s}_n{pk1.n}_K{pk1.kpad}+{pk2.kpad}", M * (pk1.flops_per_row + pk2.flops_per_row), abytes,
+                lambda: lib.cft_conv2d_chain_res(*args))
+    _lib.check(st, "cft_conv2d_chain_res")
+    return out1, out2
+
+
 # cft_bottleneck covers 64 and 128 channels (activation patch resident in LDS, weights streamed through a 4-slot LDS ring, two
 # workgroups per CU: 147-173 vs 220-234 us for the two launches it replaces at 128 channels - profiles/r02_bottleneck128.md).
 FUSED_BOTTLENECK_WIDTHS = (64, 128)
@@ -323,6 +362,59 @@ def linear(x, pk, act=ACT_NONE, residual=None, out=None, out_dtype=None):
                       out.data_ptr(), 1, 1, rows, pk.cin, x.stride(0), 0, pk.n, pk.kpad, 1, 1,
                       out.stride(0), 0, ldr, 0, act, _dt(x.dtype), _dt(out.dtype), rdt, _stream()), abytes, kind="linear")
     _lib.check(st, "cft_conv2d(linear)")
+    return out
+
+
+def splitk_choice(rows, pk, dtype):
+    """Number of K splits for ``linear_splitk`` (1 = run ``linear``): GEMMs whose 256 x 256 tiles would leave most of the 256 CUs idle and
+    whose K loop is long enough to cut (the CFT block's out_proj / fc2 at B * 128 rows) - the smallest of 2 / 4 / 8 that yields >= 192
+    workgroups, each split keeping >= 4 K steps."""
+    bk = 32 if dtype == torch.float32 else 64
+    if pk.k != 1 or pk.kpad != pk.cin or pk.cin % bk or 2 * pk.kpad * (4 if dtype == torch.float32 else 2) + 128 > 65536:
+        return 1
+    steps = pk.kpad // bk
+    t256 = -(-rows // 256) * -(-pk.n // 256)
+    if t256 >= 192:
+        return 1
+    best = 1
+    for s in (2, 4, 8):
+        if steps % s or steps // s < 4 or s * rows * pk.n >= 2 ** 31:
+            break
+        best = s
+        if t256 * s >= 192:
+            break
+    return best
+
+
+def linear_splitk(x, pk, splits):
+    """fp32 partial sums [splits, rows, pk.n] of ``x @ w.T (+ bias)`` over ``splits`` slices of K (cft_linear_splitk); summed in order they equal
+    ``linear(x, pk, out_dtype=float32)`` up to fp32 rounding.  ``layernorm_reduce`` folds them into the residual stream."""
+    _require_cuda(x, "linear_splitk")
+    rows, K = x.shape
+    if K != pk.cin or x.stride(1) != 1:
+        raise ValueError(f"linear_splitk: input [{rows},{K}] does not match packed weight (cin {pk.cin})")
+    parts = torch.empty((splits, rows, pk.n), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    abytes = rows * K * x.element_size() + splits * rows * pk.n_valid * 4 + pk.w.numel() * x.element_size()
+    st = _timed(f"linear_k{pk.k}s{pk.s}_n{pk.n}_K{pk.kpad}", rows * pk.flops_per_row, abytes,
+                lambda: lib.cft_linear_splitk(x.data_ptr(), pk.w.data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None, parts.data_ptr(),
+                                              rows, pk.cin, x.stride(0), pk.n, pk.kpad, splits, _dt(x.dtype), _stream()))
+    _lib.check(st, "cft_linear_splitk")
+    return parts
+
+
+def layernorm_reduce(x, parts, gamma, beta, out_dtype, eps=1e-5):
+    """x (float32 [rows, C], IN PLACE) += parts[0] + parts[1] + ... (float32 [n, rows, C]); returns LayerNorm(x) in ``out_dtype``."""
+    _require_cuda(x, "layernorm_reduce")
+    rows, C = x.shape
+    if parts.dtype != torch.float32 or tuple(parts.shape[1:]) != (rows, C) or not parts.is_contiguous() or not x.is_contiguous() or x.dtype != torch.float32:
+        raise ValueError(f"layernorm_reduce: x {tuple(x.shape)} {x.dtype} / parts {tuple(parts.shape)} {parts.dtype} must be contiguous fp32 with matching rows")
+    out = torch.empty((rows, C), dtype=out_dtype, device=x.device)
+    lib = _lib.load()
+    st = _timed("cft_layernorm", 0.0, rows * C * (8.0 + 4.0 * parts.shape[0] + out.element_size()),
+                lambda: lib.cft_layernorm_reduce(x.data_ptr(), parts.data_ptr(), parts.shape[0], gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                                 rows, C, eps, _dt(out_dtype), _stream()))
+    _lib.check(st, "cft_layernorm_reduce")
     return out
 
 

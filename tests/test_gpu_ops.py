@@ -255,6 +255,77 @@ def test_conv2d_chain_is_bit_identical_to_two_launches(dev, dtype, B, H, W, cin,
         ops.conv2d_chain(x, pk_bad, pk2_bad, ops.ACT_SILU)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("B,H,W,k,n2", [(2, 40, 40, 3, 256), (1, 19, 23, 3, 256), (3, 16, 16, 3, 64), (1, 40, 40, 1, 256), (64, 40, 40, 3, 256)])
+def test_conv2d_chain_res_is_bit_identical_to_two_launches(dev, dtype, B, H, W, k, n2):
+    """cft_conv2d_chain_res - Bottleneck j's 3x3 conv WITH its shortcut and Bottleneck j + 1's 1x1 conv in one kernel (256 channels): the
+    shortcut tile is added in fp32 before the one rounding, exactly like the plain epilogue does -> y1 and y2 are bit-identical to
+    conv2d(x, pk1, residual=res) followed by conv2d(y1, pk2); full tiles (the bench's 64 x 40 x 40), pixel tails, a narrow second layer, a 1x1
+    first layer, y1 written in place over the shortcut, channel-slice outputs."""
+    from msod_amd import ops
+    cin = 256
+    x = to_dev_nhwc(_q(_rnd(B, cin, H, W, seed=41), dtype), dev, dtype)
+    res = to_dev_nhwc(_q(_rnd(B, 256, H, W, seed=42), dtype), dev, dtype)
+    pk1 = ops.pack_conv(_rnd(256, cin, k, k, seed=43) * (2.0 / (cin * k * k)) ** 0.5, _rnd(256, seed=44) * 0.1, dtype, device=dev)
+    pk2 = ops.pack_conv(_rnd(n2, 256, 1, 1, seed=45) * (2.0 / 256) ** 0.5, _rnd(n2, seed=46) * 0.1, dtype, device=dev)
+    assert ops.conv2d_chain_res_ok(x, pk1, pk2)
+    y1_two = ops.conv2d(x, pk1, ops.ACT_SILU, residual=res)
+    y2_two = ops.conv2d(y1_two, pk2, ops.ACT_SILU)
+    y1, y2 = ops.conv2d_chain_res(x, pk1, res, pk2, ops.ACT_SILU)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y1_two) and torch.equal(y2, y2_two) and float(y2.float().abs().max()) > 0.1
+    # channel-slice outputs, y1 in place over the shortcut
+    buf1 = ops.new_nhwc(B, H, W, 256 + 16, dtype, dev); buf1.zero_()
+    buf2 = ops.new_nhwc(B, H, W, pk2.n + 8, dtype, dev); buf2.zero_()
+    ops.conv2d_chain_res(x, pk1, res, pk2, ops.ACT_SILU, out1=buf1[:, 8:264], out2=buf2[:, :pk2.n])
+    res2 = res.clone()
+    y1_ip, y2_ip = ops.conv2d_chain_res(x, pk1, res2, pk2, ops.ACT_SILU, out1=res2)
+    torch.cuda.synchronize()
+    assert torch.equal(buf1[:, 8:264], y1_two) and torch.equal(buf2[:, :pk2.n], y2_two)
+    assert float(buf1[:, :8].float().abs().max()) == 0.0 and float(buf1[:, 264:].float().abs().max()) == 0.0 and float(buf2[:, pk2.n:].float().abs().max()) == 0.0
+    assert torch.equal(res2, y1_two) and torch.equal(y2_ip, y2_two)
+    pk128 = ops.pack_conv(_rnd(128, cin, k, k, seed=47), None, dtype, device=dev)            # 128-channel first layers: the Bottleneck kernel's domain
+    pk2b = ops.pack_conv(_rnd(128, 128, 1, 1, seed=48), None, dtype, device=dev)
+    assert not ops.conv2d_chain_res_ok(x, pk128, pk2b)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "fp16", "f32"])
+@pytest.mark.parametrize("rows,n,K,splits", [(1024, 1024, 4096, 2), (1024, 512, 2048, 4), (520, 256, 1024, 4), (1024, 1024, 1024, 2), (256, 320, 1280, 4), (8192, 1024, 4096, 2)])
+def test_linear_splitk_and_layernorm_reduce(dev, dtype, rows, n, K, splits):
+    """cft_linear_splitk: fp32 partial sums over slices of K (bias in slice 0) - summed they equal the one-launch fp32-output linear up to
+    fp32 summation order; identical from run to run.  cft_layernorm_reduce: x += sum of the parts (in order), y = LayerNorm(x), vs torch."""
+    from msod_amd import ops
+    x = _q(_rnd(rows, K, seed=51), dtype).to(dev).to(dtype)
+    pk = ops.pack_conv(_rnd(n, K, seed=52) * (1.0 / K) ** 0.5, _rnd(n, seed=53) * 0.1, dtype, device=dev)
+    one = ops.linear(x, pk, out_dtype=torch.float32)
+    parts = ops.linear_splitk(x, pk, splits)
+    parts2 = ops.linear_splitk(x, pk, splits)
+    torch.cuda.synchronize()
+    assert parts.shape == (splits, rows, pk.n) and torch.equal(parts, parts2)
+    tot = parts.sum(0)
+    assert (tot - one).abs().max().item() <= 2e-5 * max(1.0, one.abs().max().item()) * (8 if dtype == torch.float32 else 1)
+    assert float(parts[1].abs().max()) > 0.01                                # every slice carries its share
+    # the slices are what they claim to be: slice s = x[:, s*K/S:(s+1)*K/S] @ w[:, same].T (+ bias for s = 0), against torch in fp32
+    kc = K // splits
+    wf = pk.w[:n, :K].float()
+    for s_ in (0, splits - 1):
+        want = x[:, s_ * kc:(s_ + 1) * kc].float() @ wf[:, s_ * kc:(s_ + 1) * kc].T + (pk.bias[:n] if s_ == 0 else 0.0)
+        assert (parts[s_][:, :n] - want).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item())
+    res = _rnd(rows, pk.n, seed=54).to(dev)
+    gamma, beta = (1.0 + 0.1 * _rnd(pk.n, seed=55)).to(dev), (0.1 * _rnd(pk.n, seed=56)).to(dev)
+    xr = res.clone()
+    y = ops.layernorm_reduce(xr, parts, gamma, beta, dtype)
+    want_x = res.clone()
+    for s_ in range(splits):
+        want_x += parts[s_]
+    want_y = torch.nn.functional.layer_norm(want_x, (pk.n,), gamma, beta, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(xr, want_x)                                           # fixed order: bit-exact running sum
+    assert (y.float() - want_y).abs().max().item() <= (1e-4 if dtype == torch.float32 else 4e-2)
+    assert ops.splitk_choice(8192, ops.pack_conv(torch.zeros(1024, 4096), None, torch.bfloat16, device=dev), torch.bfloat16) == 2
+    assert ops.splitk_choice(8192, ops.pack_conv(torch.zeros(4096, 1024), None, torch.bfloat16, device=dev), torch.bfloat16) == 1
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_conv2d_chain_random_geometries(dev, seed):
     """Seeded sweep over what cft_conv2d_chain_ok accepts (first layer 1x1 / 3x3 / 5x5, stride 1 / 2, 64..320 input channels, odd image

@@ -74,6 +74,18 @@ PY
     run "depth-first 8 chunks, rows 0-4" --depth-first 8
     run "depth-first 8, one forward in flight" --depth-first 8 --in-flight 1
     run "layer by layer, one forward in flight" --in-flight 1 ;;
+  r5b)         # round 5: chained 3x3 (+ shortcut) + 1x1 kernel, split-K linears + LayerNorm-reduce: op / model tests, A/B on the forward
+    timeout 1500 python -m pytest tests/test_gpu_model.py tests/test_gpu_ops.py -q -m gpu -x -k "chain or splitk or layernorm or attention or cft_output_fusion or graph_replay or train_forward" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -5 $O/tests.log
+    X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
+    run() { tag=$1; shift; timeout 400 python bench.py $X "$@" > $O/b.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/b.json'));r=d['roofline'];print('$tag', d['value'], d['ms_per_step'], (d.get('single_in_flight') or {}).get('value'), r['whole_step']['frac'], r['by_block']['cft_block_whole']['ms'], r['by_block']['cft_block_whole']['frac'], d['config'].get('stream_group_probe_ms_per_step'))" | tee -a $O/summary.txt; }
+    run "default (chain + splitk)"; cp gpurun_out/bench_families.json $O/families_default.json
+    run "no splitk" --no-splitk; cp gpurun_out/bench_families.json $O/families_nosplitk.json
+    run "no conv chain" --no-conv-chain; cp gpurun_out/bench_families.json $O/families_nochain.json
+    run "default (chain + splitk)"
+    run "no splitk" --no-splitk
+    run "no conv chain" --no-conv-chain
+    run "bs8 default" --batch 8
+    run "bs8 no splitk" --batch 8 --no-splitk ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
