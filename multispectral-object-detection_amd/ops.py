@@ -365,6 +365,9 @@ def linear(x, pk, act=ACT_NONE, residual=None, out=None, out_dtype=None):
     return out
 
 
+SPLITK_MAX_ROWS = 2048      # token rows (B * 128) up to which split-K pays: <= 16 pairs per GPU (BASELINE config 5's per-rank regime, small batches)
+
+
 def splitk_choice(rows, pk, dtype):
     """Number of K splits for ``linear_splitk`` (1 = run ``linear``): GEMMs whose 256 x 256 tiles would leave most of the 256 CUs idle and
     whose K loop is long enough to cut (the CFT block's out_proj / fc2 at B * 128 rows) - the smallest of 2 / 4 / 8 that yields >= 192
@@ -374,7 +377,10 @@ def splitk_choice(rows, pk, dtype):
         return 1
     steps = pk.kpad // bk
     t256 = -(-rows // 256) * -(-pk.n // 256)
-    if t256 >= 192:
+    # Measured (profiles/r05_splitk_ab.md): at 8192 rows (64 pairs) the split GEMMs gain 0.31 ms per forward and the LayerNorms that fold
+    # 2-4 x [rows, d] fp32 partial sums lose 0.50 ms (HBM bytes); at 1024 rows (8 pairs) everything is latency-bound and the CFT block drops
+    # from 2.37 to 1.84 ms.  So: only where the un-split GEMM leaves >= 3/4 of the chip idle.
+    if t256 >= 64 or rows > SPLITK_MAX_ROWS:
         return 1
     best = 1
     for s in (2, 4, 8):

@@ -120,6 +120,118 @@ __global__ void __launch_bounds__(512) dma_kernel(const unsigned char* w, const 
   if (sink != nullptr && smem[tid * 16] == 123 && nsteps < 0) sink[tid] = 1;
 }
 
+// Round 5: the one tile shape that halves the fragment reads again - FOUR waves per workgroup, one per SIMD, each a
+// 128 x 128 wave tile of 4 x 4 v_mfma_f32_32x32x16_bf16 tiles (256 accumulator registers, the other half of the 512-entry file for
+// fragments): per 256 x 256 x 64 K step a wave reads 16 + 16 fragments (ds_read_b128, slot ^ ((row >> 1) & 7): conflict-free for the 32-row
+// operand layout) for 64 MFMAs = 0.25 reads per 16-KFLOP MFMA-equivalent (shipped 16-wave kernel 0.5, the 8-wave kernel 0.375), issues 16
+// LDS-DMA requests (64 KiB per step per CU, two 64-KiB buffers) and meets ONE barrier.  The fragments of k chunk c + 1 are read under the
+// MFMAs of chunk c (two register sets).  WORK: 1 = reads, 2 = MFMAs, 4 = NO DMA stream.  Kill criterion: all three <= 1.30 us per step.
+template <int WORK>
+__global__ void __launch_bounds__(256) dma4_kernel(const unsigned char* w, const unsigned char* x, int nsteps, long x_rows_per_wg, int* sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int STAGE = 65536;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r0 = tid >> 3, g = tid & 7;                         // 32 rows x 8 granules per pass, 16 passes per stage
+  const unsigned char* wsrc[8];
+  const unsigned char* xsrc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = r0 + i * 32;
+    wsrc[i] = w + (long)row * 4608 + (g ^ ((row >> 1) & 7)) * 16;
+    xsrc[i] = x + ((long)blockIdx.x * x_rows_per_wg + row) * 512 + (g ^ ((row >> 1) & 7)) * 16;
+  }
+  f32x16_t acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  u32x4_t fa[2][4], fb[2][4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[q][i] = u32x4_t{0x3f803f80u + (unsigned)lane * 77u + i, 0x3f903fa0u ^ (unsigned)(tid << 3), 0xbf803f00u + i * 5u, 0x3f003f40u};
+      fb[q][i] = u32x4_t{0x3f813f82u + (unsigned)lane * 31u + i, 0xbf903fa0u ^ (unsigned)(tid << 2), 0x3f803f10u + i * 7u, 0xbf003f40u};
+    }
+  const unsigned rrow = (unsigned)(lane & 31), rgrp = (unsigned)(lane >> 5), rswz = (rrow >> 1) & 7;
+  const unsigned a_base = (unsigned)(wm * 128 + rrow) * 128u, b_base = 32768u + (unsigned)(wn * 128 + rrow) * 128u;
+  int wk = 0; long xk = 0; int xc = 0;
+#define D4_READ(set_, kc_, sbase_)                                                                     \
+  if constexpr (WORK & 1) {                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+      fa[set_][i] = *reinterpret_cast<const u32x4_t*>(smem + (sbase_) + a_base + i * 4096u + ((((kc_) * 2 + rgrp) ^ rswz) << 4)); \
+      fb[set_][i] = *reinterpret_cast<const u32x4_t*>(smem + (sbase_) + b_base + i * 4096u + ((((kc_) * 2 + rgrp) ^ rswz) << 4)); \
+    }                                                                                                  \
+  }
+#define D4_MMA(set_)                                                                                   \
+  if constexpr (WORK & 2) {                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
+        acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[set_][i]), __builtin_bit_cast(bf16x8_t, fb[set_][j]), acc[i * 4 + j], 0, 0, 0); \
+  } else if constexpr (WORK & 1) {                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[set_][i]), "v"(fb[set_][i])); \
+  }
+  for (int s = 0; s < nsteps; ++s) {
+    const unsigned cur = (unsigned)(s & 1) * STAGE, nxt = cur ^ STAGE;
+    // the next step's 64 KiB: A half from the private (HBM) rows, B half from the shared (L2) matrix; four requests per k chunk
+#define D4_DMA(q_)                                                                                     \
+    if constexpr (!(WORK & 4)) {                                                                       \
+      _Pragma("unroll") for (int i = 2 * (q_); i < 2 * (q_) + 2; ++i) {                                \
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(xsrc[i] + xk), (lds_void_t*)(smem + nxt + i * 4096 + wave * 1024), 16, 0, 0);          \
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[i] + wk), (lds_void_t*)(smem + nxt + 32768 + i * 4096 + wave * 1024), 16, 0, 0);  \
+      }                                                                                                \
+    }
+    D4_READ(0, 0, cur)
+    D4_DMA(0)
+    D4_READ(1, 1, cur)
+    D4_MMA(0)
+    D4_DMA(1)
+    D4_READ(0, 2, cur)
+    D4_MMA(1)
+    D4_DMA(2)
+    D4_READ(1, 3, cur)
+    D4_MMA(0)
+    D4_DMA(3)
+    D4_MMA(1)
+    wk += 128; if (wk >= 2304) wk = 0;
+    xk += 128; xc += 128;
+    if (xc == 512) { xc = 0; xk += 256L * 512 - 512; }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+#undef D4_READ
+#undef D4_MMA
+#undef D4_DMA
+  float sacc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sacc += acc[i][0] + acc[i][15];
+  if (sink != nullptr && sacc == 1.2345f) sink[tid] = 2;
+  if (sink != nullptr && smem[tid * 16] == 123 && nsteps < 0) sink[tid] = 1;
+}
+
+template <int WORK>
+static void run4(const unsigned char* w, const unsigned char* x, long xbytes, int ncu) {
+  auto k = dma4_kernel<WORK>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  const int nsteps = 256;
+  const long x_rows_per_wg = 256L * (nsteps * 128 / 512 + 1);
+  if ((long)ncu * x_rows_per_wg * 512 > xbytes) { printf("skip (x too small)\n"); return; }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int rep = 0; rep < 4; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(ncu), dim3(256), 131072, 0, w, x, nsteps, x_rows_per_wg, (int*)nullptr);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  const double us = best * 1e3 / nsteps;
+  printf("4 waves x 128x128 (32x32x16 MFMA), 64-KiB steps, work %d (%s%s%s): %.3f us per 256x256x64 step  = %7.1f TFLOP/s chip-equivalent, %6.1f GB/s per CU staged\n",
+         WORK, (WORK & 1) ? "reads " : "", (WORK & 2) ? "MFMAs " : "", (WORK & 4) ? "no-DMA" : "DMA", us, 2.0 * 256 * 256 * 64 * ncu / (us * 1e-6) / 1e12, 65536.0 / (us * 1e-6) / 1e9);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
 template <int ROWB, int STAGE_KIB, int DEPTH, int SRC, bool BAR, int WORK = 0>
 static void run(const unsigned char* w, const unsigned char* x, long xbytes, int ncu) {
   constexpr int STAGE = STAGE_KIB * 1024;
@@ -175,7 +287,7 @@ __global__ void fill_bf16(unsigned* p, long n_words) {
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
   const int ncu = p.multiProcessorCount;
   printf("%s, %d CUs\n", p.name, ncu);
@@ -185,6 +297,17 @@ int main() {
   hipLaunchKernelGGL(fill_bf16, dim3(1024), dim3(256), 0, 0, (unsigned*)w, wbytes / 4);
   hipLaunchKernelGGL(fill_bf16, dim3(8192), dim3(256), 0, 0, (unsigned*)x, xbytes / 4);
   hipDeviceSynchronize();
+  printf("== round 5: four waves x 128x128 wave tiles (one wave per SIMD, accumulators in 256 registers), half L2 / half HBM sources ==\n");
+  run4<6>(w, x, xbytes, ncu);    // MFMAs alone
+  run4<5>(w, x, xbytes, ncu);    // reads alone
+  run4<0>(w, x, xbytes, ncu);    // DMA alone
+  run4<7>(w, x, xbytes, ncu);    // MFMAs + reads
+  run4<2>(w, x, xbytes, ncu);    // MFMAs + DMA
+  run4<1>(w, x, xbytes, ncu);    // reads + DMA
+  run4<3>(w, x, xbytes, ncu);    // all three: a GEMM K loop without its epilogue
+  printf("   (reference rows of the 8-wave / 128x64 form, same sources: work 0 = DMA, 2 = + MFMAs, 3 = + reads)\n");
+  run<128, 64, 1, 2, true, 0>(w, x, xbytes, ncu); run<128, 64, 1, 2, true, 2>(w, x, xbytes, ncu); run<128, 64, 1, 2, true, 3>(w, x, xbytes, ncu);
+  if (argc > 1 && argv[1][0] == '4') { hipFree(w); hipFree(x); return 0; }
   printf("== weight-like source (shared, L2 hits) ==\n");      sweep<0, true>(w, x, xbytes, ncu);
   printf("== activation-like source (private, HBM stream) ==\n"); sweep<1, true>(w, x, xbytes, ncu);
   printf("== half / half (a GEMM K step) ==\n");                sweep<2, true>(w, x, xbytes, ncu);
