@@ -319,6 +319,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2, help="forwards in flight (own graphs, buffers and streams each); 1 = one at a time")
     ap.add_argument("--force-gather", action="store_true", help="N = 1: run the detection all-gather anyway (RCCL with world size 1, OverlappedGather "
                     "inside the timed steps) and report multi_gpu_selfcheck - exercises the N > 1 step mode on the one GPU of a box")
+    ap.add_argument("--no-stem", action="store_true", help="A/B: Focus, then the chained Conv + C3.cv1|cv2 (round 4) instead of the one-kernel stem")
     ap.add_argument("--no-splitk", action="store_true", help="A/B: the CFT blocks' out_proj / fc2 as one launch each (round 4) instead of split-K + LayerNorm-reduce")
     ap.add_argument("--depth-first", default="", help="CHUNKS[,ROWS]: Model.depth_first - the image-only prefix of each backbone sub-batch by sub-batch "
                     "(Infinity-Cache residency); empty = layer by layer over the whole batch")
@@ -352,6 +353,7 @@ def main():
     model.fuse_cft_outputs = not args.no_cft_fusion
     model.chain_convs = not args.no_conv_chain
     model.splitk = not args.no_splitk
+    model.fuse_stem = not args.no_stem
     if args.depth_first:
         df = [int(v) for v in args.depth_first.split(",")]
         model.depth_first = (df[0], df[1] if len(df) > 1 else None)

@@ -15,6 +15,7 @@
 // The products, the 32-wide k chunks and their order are those of the generic path, so the result is
 // bit-identical to it (tests/test_gpu_ops.py).
 #include "cft_common.h"
+#include "focus_common.h"
 
 struct FocusConvParams {
   const unsigned char* in;
@@ -26,27 +27,6 @@ struct FocusConvParams {
   int kpad, ldy, yoff;
   int Ho, Wo, tiles_x, bands;
 };
-
-template <typename IN>
-__device__ __forceinline__ void load_pair(const IN* p, float scale, float& a, float& b);
-template <>
-__device__ __forceinline__ void load_pair<float>(const float* p, float scale, float& a, float& b) {
-  const float2 t = *reinterpret_cast<const float2*>(p);
-  a = t.x * scale;
-  b = t.y * scale;
-}
-template <>
-__device__ __forceinline__ void load_pair<f16_t>(const f16_t* p, float scale, float& a, float& b) {   // half images (`img.half()`, test.py:107)
-  const f32x2_t t = __builtin_convertvector(*reinterpret_cast<const f16x2_t*>(p), f32x2_t);
-  a = t[0] * scale;
-  b = t[1] * scale;
-}
-template <>
-__device__ __forceinline__ void load_pair<unsigned char>(const unsigned char* p, float scale, float& a, float& b) {
-  const unsigned short t = *reinterpret_cast<const unsigned short*>(p);
-  a = (float)(t & 0xffu) * scale;
-  b = (float)(t >> 8) * scale;
-}
 
 template <typename T, typename IN, int NT, int ACT>   // T: uint16_t (bf16) or f16_t compute/output; IN: image element
 __global__ void __launch_bounds__(512) focus_conv_kernel(const FocusConvParams p) {

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .common import (GPT, NMS, SPP, Add, Add2, Bottleneck, C3, Concat, Conv, Focus, PendingBilinear, PendingConv, Upsample, _Packed, autoShape, resolve,
+from .common import (GPT, NMS, SPP, Add, Add2, Bottleneck, C3, Concat, Conv, Focus, PendingBilinear, PendingConv, PendingFocus, Upsample, _Packed, autoShape, resolve,
                      ACT_NONE, invalidate_packed)
 
 logger = logging.getLogger(__name__)
@@ -359,6 +359,7 @@ class Model(nn.Module):
             self.__dict__.get("_graphs", {}).clear()
         return property(get, set_, doc=doc)
 
+    fuse_stem = _switch("fuse_stem", True, "Run Focus + the stride-2 Conv + the following C3's cv1|cv2 as one kernel where ops.stem_ok allows (yolov5l widths).")
     fuse_cft_outputs = _switch("fuse_cft_outputs", True, "Run the two Add2 layers behind a GPT block and the Add that sums them as one kernel (cft_fusion_plan).")
     plan_concats = _switch("plan_concats", True, "Let Conv / C3 / Add layers that feed a head Concat write straight into their slice of its buffer (concat_plan).")
     depth_first = _switch("depth_first", None,
@@ -522,8 +523,14 @@ class Model(nn.Module):
     def _run_layer(self, m, x, x2, cbufs, chain=True):
         """``chain=False`` (profiling walks): every layer issues its own launches, so the per-layer table charges a Conv's time to the
         Conv and not to the C3 that would otherwise run it."""
-        if m.f == -4:
-            return m(x2)
+        if m.f == -4 or (m.i == 0 and isinstance(m, Focus)):
+            img = x2 if m.f == -4 else x
+            if (chain and self.fuse_stem and self.chain_convs and cbufs is not None and not self.training and isinstance(m, Focus)
+                    and (m.i + 1) in self.chain_plan() and isinstance(img, torch.Tensor) and img.is_cuda):
+                dt = m.compute_dtype or m.conv.conv.weight.dtype
+                if dt in (torch.bfloat16, torch.float16):
+                    return PendingFocus(m, img, dt)       # left to the C3 two rows down: Focus + Conv + cv1|cv2 as one kernel (ops.stem)
+            return m(img)
         tgt = self.concat_plan().get(m.i) if cbufs is not None else None
         if tgt is not None:
             cidx, off, c, total = tgt
@@ -543,7 +550,7 @@ class Model(nn.Module):
         if cbufs is not None and isinstance(m, Concat) and m.i in cbufs:
             return m(x, out=cbufs[m.i])
         if (chain and cbufs is not None and not self.training and m.i in self.chain_plan() and self.chain_convs
-                and isinstance(x, torch.Tensor) and x.dtype in (torch.bfloat16, torch.float16)):
+                and isinstance(x, (torch.Tensor, PendingFocus)) and x.dtype in (torch.bfloat16, torch.float16)):
             return PendingConv(m, x)                 # left to the C3 behind it (one kernel for the conv and the C3's cv1|cv2)
         return m(x)
 
