@@ -277,8 +277,15 @@ def test_stem_is_bit_identical_to_focus_then_the_chained_conv(dev, dtype, img_dt
     f = ops.focus_conv(img, pkf, ops.ACT_SILU, dtype)
     two = ops.conv2d_chain(f, pk1, pk2, act2)
     one = ops.stem(img, pkf, pk1, pk2, act2, dtype)
+    from msod_amd import _lib
+    old_variant = _lib.load().cft_set_conv_variant(8816)          # the 8 x 16-tile, one-workgroup-per-CU form of the kernel
+    try:
+        one16 = ops.stem(img, pkf, pk1, pk2, act2, dtype)
+    finally:
+        _lib.load().cft_set_conv_variant(old_variant)
     torch.cuda.synchronize()
     assert one.shape == two.shape and torch.equal(one, two) and float(two.float().abs().max()) > 0.05
+    assert torch.equal(one16, two)
     Ho, Wo = two.shape[2], two.shape[3]
     buf = ops.new_nhwc(B, Ho, Wo, pk2.n + 24, dtype, dev)
     buf.zero_()
