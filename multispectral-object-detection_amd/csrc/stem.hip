@@ -4,23 +4,28 @@
 //
 // As separate launches (cft_focus_conv, then cft_conv2d_chain) the Focus output - [B, 320, 320, 64] at 640 x 640: 839 MB per stream at 64
 // pairs - is written once and read once: 3.4 GB of a forward's 48 GB of HBM traffic, for 1.3 % of its FLOPs.  Here it never exists:
-//   * a persistent 8-wave workgroup per CU walks 8 x 16-pixel tiles of the stride-2 conv's output (XCD-aware order: spatial neighbours
-//     share image rows in one L2);
-//   (a) the 19 x 35 halo patch of the space-to-depth tensor is built in LDS straight from the image (two parity planes of 32-byte pixels,
-//       so that stride-2 pixel walks are stride-1 in LDS); the NEXT tile's image samples are requested right behind it and land in
-//       registers under everything that follows;
-//   (b) Focus: F = SiLU(Wf s2d + bf) on the 17 x 33 halo patch the stride-2 conv needs (561 pixels, 36 MFMA row tiles; the Focus weights
-//       are the ROW operand, held in registers: a lane ends up with 4 consecutive channels of a pixel), rounded once and written to an LDS
-//       patch of 128-byte pixels (even / odd columns de-interleaved per row, granule slot ^ (pixel & 7)); pixels outside the image are
-//       ZERO (= the stride-2 conv's padding, not Focus of padding);
+//   * persistent 8-wave workgroups, TWO per CU (73 KiB of LDS each), walk 8 x 8-pixel tiles of the stride-2 conv's output in an XCD-aware
+//     order (spatial neighbours share image rows in one L2);
+//   (a) the 19 x 19 halo patch of the space-to-depth tensor is built in LDS straight from the image (two column-parity planes of 32-byte
+//       pixels, so that stride-2 pixel walks are stride-1 in LDS); the NEXT tile's image samples are requested late in the tile and land
+//       in registers under its tail;
+//   (b) Focus: F = SiLU(Wf s2d + bf) on the 17 x 17 halo patch the stride-2 conv needs (289 pixels, 19 MFMA row tiles; the Focus weights
+//       are the ROW operand: a lane ends up with 4 consecutive channels of a pixel), rounded once and written to an LDS patch of 128-byte
+//       pixels (even / odd columns de-interleaved per row); pixels outside the image are ZERO (= the stride-2 conv's padding, not Focus
+//       of padding);
 //   (c) the stride-2 3x3 conv reads its nine taps as shifted ds_read_b128 of that patch; only its weights stream - one tap (128 rows x
-//       128 B = 16 KiB) per stage through a 4-slot LDS ring, three stages ahead, counted s_waitcnt;
+//       128 B = 16 KiB) per stage through a two-slot LDS ring;
 //   (d) bias + SiLU + rounding on the accumulators, which are written to LDS as the A operand of the pointwise GEMM (two swizzled
-//       [128 pixels][64 channels] images over the dead patch; lanes l / l^1 swap half of their values so that every write is a packed
+//       [64 pixels][64 channels] images over the dead patch; lanes l / l^1 swap half of their values so that every write is a packed
 //       channel pair); its weights arrive as ring stages 9 and 10;
 //   (e) epilogue: bias + activation -> fp32 strip -> 16-byte row vectors -> 16-bit NHWC stores (as conv_gemm.hip).
 // Products, 32-wide k chunks, their order and every rounding are those of cft_focus_conv followed by cft_conv2d_chain: bit-identical to
 // them (tests/test_gpu_ops.py).
+// MEASURED (profiles/r05_stem.md): 905 us per launch against 376 + 541 us for the two kernels back to back, 943 against 313 + 463 inside the
+// forward, -1 % pairs/s on the whole forward: the tile loop is a chain of ~14 barriers and exposed L2 / HBM round trips that two workgroups
+// per CU do not hide (the skeleton alone - barriers, patch build, image writes, pointwise GEMM - costs 6.4 us per tile).  An 8 x 16-tile,
+// one-workgroup-per-CU form measured 1020 - 1030 us and was removed.  The kernel is therefore OPT-IN (Model.fuse_stem, default off): it
+// trades 7 % of the forward's HBM traffic for no time.
 #include "cft_common.h"
 #include "focus_common.h"
 
@@ -42,324 +47,11 @@ struct StemParams {
   int ldy, yoff, N2, act2;
   int Hf, Wf, Ho, Wo;       // Focus output (= space-to-depth) size, stride-2 conv output size
   int tiles_x, tiles_y, ntiles;
+  int abl;                  // timing probes of stem8_kernel (results wrong; cft_set_conv_variant(8800 + bits)): 1 no weight ring, 2 no Focus phase, 4 no conv taps, 8 no epilogue, 16 no image samples
 };
 
-template <typename T, typename IN>
-__global__ void __launch_bounds__(512) stem_kernel(const StemParams p) {
-  constexpr int TH = 8, TW = 16;
-  constexpr int FPW = 33, NFP = 17 * FPW;                     // F halo patch: 17 x 33 = 561 pixels
-  constexpr int NRT = 36;                                     // its MFMA row tiles (576 slots)
-  constexpr int SPW = 35, NSP = 19 * SPW;                     // s2d halo patch: 19 x 35 = 665 pixels
-  constexpr int SCOLS = 18;                                   // storage columns per column parity
-  constexpr int F_BYTES = NRT * 16 * 128;                     // 73728
-  constexpr int SLOT = 16384;
-  constexpr int S_BYTES = 19 * 2 * SCOLS * 32;                // 21888
-  constexpr int IMG = 128 * 128;                              // one [128 pixels][64 channels] image of the pointwise GEMM's A operand
-  constexpr int SLD = 64 + 4;
-  static_assert(TH == 8 && TW == 16, "wave layout: 4 row pairs x 2 channel halves");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sF = smem;
-  unsigned char* sR = smem + F_BYTES;
-  unsigned char* sS = sR + 4 * SLOT;
-  unsigned char* sZ = sS + S_BYTES;                           // a zero granule: the 10th (all-zero) tap of the Focus conv's padded K
-  float* sB = reinterpret_cast<float*>(sZ + 16);              // bf[64], b1[128], b2[128]
-
-  const int tid0 = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-  const int wmr = wave >> 1, wnc = wave & 1;                  // stride-2 conv / pointwise GEMM: tile rows 2 wmr, 2 wmr + 1, channels 64 wnc .. + 64
-  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(cft_zero_page_st);
-  const uint32_t fl = (uint32_t)(uintptr_t)(lds_void_t*)sF;
-
-  // ---- once per workgroup: biases, the zero granule
-  if (tid0 < 64) sB[tid0] = p.bf != nullptr ? p.bf[tid0] : 0.0f;
-  else if (tid0 < 192) sB[tid0] = p.b1 != nullptr ? p.b1[tid0 - 64] : 0.0f;
-  else if (tid0 < 320) sB[tid0] = (p.b2 != nullptr && tid0 - 192 < p.N2) ? p.b2[tid0 - 192] : 0.0f;
-  if (tid0 == 320) *reinterpret_cast<gran_t*>(sZ) = gran_t{0u, 0u, 0u, 0u};
-
-  // ring stage s: 0..8 = tap s of the stride-2 conv's weights (128 rows x 64 k), 9 / 10 = k half of the pointwise weights; slot s & 3;
-  // row r, k-granule g of the stage in 16-byte slot g ^ (r & 7) (the XOR on the source side: the LDS-DMA destination is linear)
-#define STEM_STAGE(s_)                                                                                   \
-  {                                                                                                      \
-    constexpr int ss_ = (s_);                                                                            \
-    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                   \
-      const int row_ = r1 + h_ * 64;                                                                     \
-      const unsigned char* src_ = ss_ < 9 ? p.w1 + ((long)row_ * 576 + ss_ * 64 + g1 * 8) * 2            \
-                                          : (row_ < p.N2 ? p.w2 + ((long)row_ * 128 + (ss_ - 9) * 64 + g1 * 8) * 2 : zero_page); \
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(sR + (ss_ & 3) * SLOT + h_ * 8192 + wave * 1024), 16, 0, 0); \
-    }                                                                                                    \
-  }
-#define STEM_SYNC(n_)                                                                                    \
-  {                                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    __builtin_amdgcn_s_waitcnt((n_) | 0x70);              /* vmcnt(n) lgkmcnt(0) */                      \
-    __builtin_amdgcn_s_barrier();                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-  }
-
-  // ---- tile walk: workgroup b takes virtual slots b, b + G, b + 2 G, ... of the XCD-aware order (host: G % 8 == 0 or G == ntiles, so a
-  // workgroup's slots stay on its XCD and consecutive LOGICAL tiles - spatial neighbours - run on one XCD at about the same time)
-  const int nt = p.ntiles, xq = nt >> 3, xr = nt & 7;
-  const int tiles = p.tiles_x * p.tiles_y;
-  const IN* img_base = reinterpret_cast<const IN*>(p.in);
-  float raw[2][12];
-// request the 12 image samples of this thread's two s2d patch pixels for tile (b_, oy0_, ox0_): unconditional loads at clamped coordinates
-// (every wave issues the same number of requests - the counted waits below rely on it), masked when the patch is built
-#define STEM_FETCH(b_, oy0_, ox0_)                                                                       \
-  {                                                                                                      \
-    const IN* img_ = img_base + (long)(b_) * p.sb;                                                       \
-    _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                                   \
-      const int si_ = min(tid + r_ * 512, NSP - 1);                                                      \
-      const int sy_ = (si_ * 1873) >> 16, sx_ = si_ - sy_ * SPW;                                         \
-      const int zy_ = min(max(2 * (oy0_) - 2 + sy_, 0), p.Hf - 1), zx_ = min(max(2 * (ox0_) - 2 + sx_, 0), p.Wf - 1); \
-      _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_) {                                                 \
-        const IN* base_ = img_ + (long)c_ * p.sc + (long)(2 * zy_) * p.sh + 2 * zx_;                     \
-        load_pair<IN>(base_, p.scale, raw[r_][0 + c_], raw[r_][6 + c_]);        /* (dy=0,dx=0), (dy=0,dx=1) */ \
-        load_pair<IN>(base_ + p.sh, p.scale, raw[r_][3 + c_], raw[r_][9 + c_]); /* (dy=1,dx=0), (dy=1,dx=1) */ \
-      }                                                                                                  \
-    }                                                                                                    \
-  }
-#define STEM_DECODE(v_, lt_, b_, oy0_, ox0_)                                                             \
-  const int xcd_##v_ = (v_) & 7, xslot_##v_ = (v_) >> 3;                                                 \
-  const int lt_ = (xcd_##v_ < xr ? xcd_##v_ * (xq + 1) : xr * (xq + 1) + (xcd_##v_ - xr) * xq) + xslot_##v_; \
-  const int b_ = lt_ / tiles, tt_##v_ = lt_ - b_ * tiles;                                                \
-  const int ty_##v_ = tt_##v_ / p.tiles_x, tx_##v_ = tt_##v_ - ty_##v_ * p.tiles_x;                      \
-  const int oy0_ = ty_##v_ * TH, ox0_ = tx_##v_ * TW;
-
-  int vslot = blockIdx.x;
-  if (vslot < nt) {
-    const int tid = tid0;
-    STEM_DECODE(vslot, lt0, b0, oy00, ox00)
-    STEM_FETCH(b0, oy00, ox00)
-  }
-  __syncthreads();                                            // biases / zero granule visible
-
-  for (; vslot < nt; vslot += gridDim.x) {
-    // per-lane indices are re-derived from an opaque copy of the thread id in every iteration: otherwise the compiler hoists ~60 registers
-    // of loop-invariant addresses (11 ring stages x 2 rows, fragment offsets ...) out of the persistent loop and spills
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, lrow = lane & 15, lgrp = lane >> 4;
-    const int r1 = tid >> 3, g1 = (tid & 7) ^ (r1 & 7);
-    const unsigned char* wf_lane = p.wf + ((long)lrow * 192 + lgrp * 8) * 2;     // this lane's granule of Focus weight row lrow (+ 16 j rows, + 4 ks granules)
-    STEM_DECODE(vslot, lt, b, oy0, ox0)
-    const int fy0 = 2 * oy0 - 1, fx0 = 2 * ox0 - 1;           // F patch origin in the Focus output; the s2d patch starts one pixel earlier
-    // ---- (a) s2d halo patch: registers -> 16 channels (12 real + 4 zero) -> two granules per pixel
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int si = tid + r * 512;
-      if (si < NSP) {
-        const int sy = (si * 1873) >> 16, sx = si - sy * SPW;
-        const bool in_img = (unsigned)(fy0 - 1 + sy) < (unsigned)p.Hf && (unsigned)(fx0 - 1 + sx) < (unsigned)p.Wf;
-        float v[16];
-#pragma unroll
-        for (int e = 0; e < 12; ++e) v[e] = in_img ? raw[r][e] : 0.0f;
-        v[12] = v[13] = v[14] = v[15] = 0.0f;
-        gran_t* o = reinterpret_cast<gran_t*>(sS + ((sy * 2 + (sx & 1)) * SCOLS + (sx >> 1)) * 32);
-        o[0] = Elem<T>::pack(v);
-        o[1] = Elem<T>::pack(v + 8);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // the Focus weights as MFMA row-operand fragments: 20 granules per lane, re-read per tile (24 KiB shared by every workgroup: L1 / L2 hits)
-    // instead of living in registers across the whole tile; oldest requests of the tile, so the counted waits below cover them
-    gran_t wfrag[5][4];
-#pragma unroll
-    for (int ks = 0; ks < 5; ++ks)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        wfrag[ks][j] = *reinterpret_cast<const gran_t*>(wf_lane + ((long)j * 16 * 192 + ks * 32) * 2);
-    __builtin_amdgcn_sched_barrier(0);
-    {   // the next tile's image samples (older than every ring stage of this tile: the first counted wait covers them)
-      const int vnext = vslot + gridDim.x;
-      if (vnext < nt) {
-        STEM_DECODE(vnext, ltn, bn, oy0n, ox0n)
-        STEM_FETCH(bn, oy0n, ox0n)
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    STEM_STAGE(0)
-    STEM_STAGE(1)
-    STEM_STAGE(2)
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                             // the s2d patch is visible
-
-    // ---- (b) Focus on the F halo patch: row tiles wave, wave + 8, ... of 16 patch pixels each; F^T = Wf s2d^T
-#pragma unroll 1
-    for (int it = 0; it < 5; ++it) {
-      const int rt = wave + 8 * it;
-      if (rt < NRT) {                                         // wave-uniform
-        const int pq = rt * 16 + lrow, pc = min(pq, NFP - 1);
-        const int py = (pc * 1986) >> 16, rr = pc - py * FPW;
-        const int px = rr < 17 ? 2 * rr : 2 * (rr - 17) + 1;
-        const uint32_t keep = (pq < NFP && (unsigned)(fy0 + py) < (unsigned)p.Hf && (unsigned)(fx0 + px) < (unsigned)p.Wf) ? 0xffffffffu : 0u;
-        f32x4_t acc1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc1[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        gran_t af[5];
-#pragma unroll
-        for (int ks = 0; ks < 5; ++ks) {
-          const int tap = ks * 2 + (lgrp >> 1), half = lgrp & 1;
-          const int kh = tap / 3, kw = tap - kh * 3;
-          const int sy = py + kh, sx = px + kw;
-          const unsigned char* ap = tap < 9 ? sS + ((sy * 2 + (sx & 1)) * SCOLS + (sx >> 1)) * 32 + half * 16 : sZ;
-          af[ks] = *reinterpret_cast<const gran_t*>(ap);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 5; ++ks)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc1[j] = mma_granule<T>(wfrag[ks][j], af[ks], acc1[j]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int cc = j * 16 + lgrp * 4;
-          const f32x4_t bq = *reinterpret_cast<const f32x4_t*>(sB + cc);
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = apply_act<CFT_ACT_SILU>(acc1[j][e] + bq[e]);
-          uint2 w;
-          w.x = Elem<T>::pack2(v[0], v[1]) & keep;
-          w.y = Elem<T>::pack2(v[2], v[3]) & keep;
-          const uint32_t ta = fl + pq * 128 + ((((cc >> 3) ^ (pq & 7)) << 4) | ((cc & 7) << 1));
-          const unsigned long long wq = ((unsigned long long)w.y << 32) | w.x;
-          asm volatile("ds_write_b64 %0, %1" ::"v"(ta), "v"(wq) : "memory");
-        }
-      }
-    }
-    STEM_SYNC(4)                                              // the whole F patch is visible; ring stage 0 (and the prefetched image samples, older) landed
-
-    // ---- (c) stride-2 3x3 conv of the F patch: tap t = stage t in slot t & 3, two 32-wide k chunks per tap
-    f32x4_t acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int brow = (wnc * 64 + lrow) * 128;                 // this lane's row of a ring stage (j adds 16 rows)
-#define STEM_TAP(t_)                                                                                     \
-    {                                                                                                    \
-      constexpr int kh_ = (t_) / 3, kw_ = (t_) - 3 * ((t_) / 3);                                         \
-      constexpr int kwoff_ = kw_ == 0 ? 0 : (kw_ == 1 ? 17 : 1);                                         \
-      gran_t af_[2][2], bf_[2][4];                                                                       \
-      _Pragma("unroll") for (int kq = 0; kq < 2; ++kq) {                                                 \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                  \
-          const int pp_ = (2 * (2 * wmr + i) + kh_) * FPW + kwoff_ + lrow;                               \
-          af_[kq][i] = *reinterpret_cast<const gran_t*>(sF + pp_ * 128 + (((kq * 4 + lgrp) ^ (pp_ & 7)) << 4)); \
-        }                                                                                                \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
-          bf_[kq][j] = *reinterpret_cast<const gran_t*>(sR + ((t_) & 3) * SLOT + j * 2048 + brow + (((kq * 4 + lgrp) ^ (lrow & 7)) << 4)); \
-      }                                                                                                  \
-      _Pragma("unroll") for (int kq = 0; kq < 2; ++kq)                                                   \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                    \
-          _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mma_granule<T>(af_[kq][i], bf_[kq][j], acc[i][j]); \
-    }
-    // step t: request stage t + 3, multiply tap t, then wait until stage t + 1 has landed (two requests per stage and wave; the younger
-    // stages t + 2, t + 3 may stay in flight) and meet the other waves (their reads of this tap's slot are retired)
-    STEM_STAGE(3)  STEM_TAP(0) STEM_SYNC(4)
-    STEM_STAGE(4)  STEM_TAP(1) STEM_SYNC(4)
-    STEM_STAGE(5)  STEM_TAP(2) STEM_SYNC(4)
-    STEM_STAGE(6)  STEM_TAP(3) STEM_SYNC(4)
-    STEM_STAGE(7)  STEM_TAP(4) STEM_SYNC(4)
-    STEM_STAGE(8)  STEM_TAP(5) STEM_SYNC(4)
-    STEM_STAGE(9)  STEM_TAP(6) STEM_SYNC(4)
-    STEM_STAGE(10) STEM_TAP(7) STEM_SYNC(4)
-    STEM_TAP(8) STEM_SYNC(2)                                  // stage 9 landed (10 may be in flight); every wave is past its last F read
-#undef STEM_TAP
-
-    // ---- (d) bias + SiLU + rounding; the tile becomes the pointwise GEMM's A operand: image wnc = this wave's 64 channels, row = tile pixel
-    {
-      const bool odd = lane & 1;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float b1v = sB[64 + wnc * 64 + j * 16 + lrow];
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = apply_act<CFT_ACT_SILU>(acc[i][j][e] + b1v);
-          const uint32_t r01 = Elem<T>::pack2(v[0], v[1]), r23 = Elem<T>::pack2(v[2], v[3]);
-          const uint32_t got = (uint32_t)__builtin_amdgcn_mov_dpp((int)(odd ? r01 : r23), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-          const uint32_t d0 = odd ? ((got & 0xffffu) | (r23 << 16)) : ((r01 & 0xffffu) | (got << 16));
-          const uint32_t d1 = odd ? ((got >> 16) | (r23 & 0xffff0000u)) : ((r01 >> 16) | (got & 0xffff0000u));
-          const int row = (2 * wmr + i) * 16 + lgrp * 4 + (odd ? 2 : 0);
-          const int c = j * 16 + (lrow & 14);
-          unsigned char* im = sF + wnc * IMG + (c & 7) * 2;
-          *reinterpret_cast<uint32_t*>(im + row * 128 + (((c >> 3) ^ (row & 7)) << 4)) = d0;
-          *reinterpret_cast<uint32_t*>(im + (row + 1) * 128 + (((c >> 3) ^ ((row + 1) & 7)) << 4)) = d1;
-          acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    STEM_SYNC(2)                                              // images visible (stage 10 may still be in flight)
-#define STEM_PW(k2_)                                                                                     \
-    {                                                                                                    \
-      gran_t af_[2][2], bf_[2][4];                                                                       \
-      _Pragma("unroll") for (int kq = 0; kq < 2; ++kq) {                                                 \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                  \
-          const int row_ = (2 * wmr + i) * 16 + lrow;                                                    \
-          af_[kq][i] = *reinterpret_cast<const gran_t*>(sF + (k2_) * IMG + row_ * 128 + (((kq * 4 + lgrp) ^ (row_ & 7)) << 4)); \
-        }                                                                                                \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
-          bf_[kq][j] = *reinterpret_cast<const gran_t*>(sR + ((9 + (k2_)) & 3) * SLOT + j * 2048 + brow + (((kq * 4 + lgrp) ^ (lrow & 7)) << 4)); \
-      }                                                                                                  \
-      _Pragma("unroll") for (int kq = 0; kq < 2; ++kq)                                                   \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                    \
-          _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mma_granule<T>(af_[kq][i], bf_[kq][j], acc[i][j]); \
-    }
-    STEM_PW(0)
-    STEM_SYNC(0)                                              // stage 10 landed
-    STEM_PW(1)
-#undef STEM_PW
-
-    // ---- (e) epilogue: strip i = tile row 2 wmr + i, 16 pixels x 64 channels (strips live behind the images: no wave reads there now)
-    {
-      float b2v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b2v[j] = sB[192 + wnc * 64 + j * 16 + lrow];
-      float* stage = reinterpret_cast<float*>(sF + 2 * IMG) + wave * (16 * SLD);
-      const long img_pix = (long)b * p.Ho * p.Wo;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float a = acc[i][j][e] + b2v[j];
-            stage[(lgrp * 4 + e) * SLD + j * 16 + lrow] = p.act2 == CFT_ACT_SILU ? apply_act<CFT_ACT_SILU>(a) : a;
-          }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int v = 0; v < 2; ++v) {
-          const int it = lane + v * 64;
-          const int row = it >> 3, col = (it & 7) * 8;
-          const int x = ox0 + row, y = oy0 + 2 * wmr + i;
-          if (x < p.Wo && y < p.Ho && wnc * 64 + col < p.N2) {
-            const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col);
-            const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col + 4);
-            const float o[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-            *reinterpret_cast<gran_t*>(p.y + ((img_pix + (long)y * p.Wo + x) * p.ldy + p.yoff + wnc * 64 + col) * 2) = Elem<T>::pack(o);
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-    }
-    // every wave is done with the ring, the images and its strip before the next tile's stages / patches overwrite them
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-#undef STEM_STAGE
-#undef STEM_SYNC
-#undef STEM_FETCH
-#undef STEM_DECODE
-}
-
-// ------------------------------------------------------------------------------------ second form: 8 x 8 tiles, TWO workgroups per CU
-// The 8 x 16-tile kernel above owns a CU (162 KiB of LDS): its phases - patch build, Focus, nine conv taps, pointwise GEMM, epilogue - run one
-// after the other with nothing to hide a barrier, an LDS round trip or a SiLU pass behind, and it measured 1020 us per launch against 775 us
-// for cft_focus_conv + cft_conv2d_chain (profiles/r05_stem.md).  This form halves the tile (8 x 8 output pixels: F patch 17 x 17 = 38 KiB,
-// two-slot weight ring 32 KiB whose second slot first holds the s2d patch: 73 KiB) so that TWO workgroups share a CU and one's VALU / LDS /
-// barrier phases run under the other's MFMAs - what the Bottleneck kernels do.  Differences in the mapping:
+// 8 x 8 output pixels per tile: F patch 17 x 17 = 38 KiB, two-slot weight ring 32 KiB whose second slot first holds the s2d patch: 73 KiB, so
+// that TWO workgroups share a CU and one's VALU / LDS / barrier phases run under the other's MFMAs - what the Bottleneck kernels do.  Mapping:
 //   * F patch line = 17 slots (9 even columns, then 8 odd ones), granule slot ^ ((p + 3 py) & 7): the stride-2 reads of two output rows
 //     (lanes 0-7 / 8-15 of an MFMA row tile) are conflict-free;
 //   * Focus: wave (q, jh) computes row tiles q, q + 4, ... x output-channel tiles 2 jh, 2 jh + 1; its 10 weight fragments live in registers;
@@ -398,7 +90,7 @@ __global__ void __launch_bounds__(512, 2) stem8_kernel(const StemParams p) {
 #define ST8_STAGE(s_)                                                                                    \
   {                                                                                                      \
     constexpr int ss_ = (s_);                                                                            \
-    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                   \
+    if (!(p.abl & 1)) _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                 \
       const int row_ = r1 + h_ * 64;                                                                     \
       const unsigned char* src_ = ss_ < 9 ? p.w1 + ((long)row_ * 576 + ss_ * 64 + g1 * 8) * 2            \
                                           : (row_ < p.N2 ? p.w2 + ((long)row_ * 128 + (ss_ - 9) * 64 + g1 * 8) * 2 : zero_page); \
@@ -420,8 +112,8 @@ __global__ void __launch_bounds__(512, 2) stem8_kernel(const StemParams p) {
 // wave issues the same 6 requests - the counted waits rely on it), masked when the patch is built
 #define ST8_FETCH(b_, oy0_, ox0_)                                                                        \
   {                                                                                                      \
-    const IN* img_ = img_base + (long)(b_) * p.sb;                                                       \
-    const int si_ = min(tid, NSP - 1);                                                                   \
+    const IN* img_ = img_base + (long)((p.abl & 16) ? 0 : (b_)) * p.sb;                                  \
+    const int si_ = (p.abl & 16) ? 0 : min(tid, NSP - 1);                                                                   \
     const int sy_ = (si_ * 3450) >> 16, sx_ = si_ - sy_ * SPW;                                           \
     const int zy_ = min(max(2 * (oy0_) - 2 + sy_, 0), p.Hf - 1), zx_ = min(max(2 * (ox0_) - 2 + sx_, 0), p.Wf - 1); \
     _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_) {                                                   \
@@ -447,7 +139,7 @@ __global__ void __launch_bounds__(512, 2) stem8_kernel(const StemParams p) {
 
   for (; vslot < nt; vslot += gridDim.x) {
     int tid = tid0;
-    asm volatile("" : "+v"(tid));                             // (keeps ~60 registers of loop-invariant addresses from being hoisted, see above)
+    asm volatile("" : "+v"(tid));                             // opaque copy: otherwise ~60 registers of loop-invariant addresses (ring stages, fragment offsets) are hoisted out of the persistent loop
     const int lane = tid & 63, lrow = lane & 15, lgrp = lane >> 4;
     const int r1 = tid >> 3, g1 = (tid & 7) ^ (r1 & 7);
     ST8_DECODE(vslot, lt, b, oy0, ox0)
@@ -477,7 +169,7 @@ __global__ void __launch_bounds__(512, 2) stem8_kernel(const StemParams p) {
 
     // ---- (b) Focus on the F halo patch
 #pragma unroll 1
-    for (int rt = fq; rt < NRT; rt += 4) {
+    for (int rt = (p.abl & 2) ? NRT : fq; rt < NRT; rt += 4) {
       const int pq = rt * 16 + lrow, pc = min(pq, NFP - 1);
       const int py = (pc * 3856) >> 16, rr = pc - py * FPW;
       const int px = rr < 9 ? 2 * rr : 2 * (rr - 9) + 1;
@@ -538,7 +230,7 @@ __global__ void __launch_bounds__(512, 2) stem8_kernel(const StemParams p) {
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
           bf_[kq][j] = *reinterpret_cast<const gran_t*>(sR + ((t_) & 1) * SLOT + j * 2048 + brow + (((kq * 4 + lgrp) ^ (lrow & 7)) << 4)); \
       }                                                                                                  \
-      _Pragma("unroll") for (int kq = 0; kq < 2; ++kq)                                                   \
+      if (!(p.abl & 4)) _Pragma("unroll") for (int kq = 0; kq < 2; ++kq)                                 \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                    \
           _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mma_granule<T>(af_[kq][i], bf_[kq][j], acc[i][j]); \
     }
@@ -610,7 +302,12 @@ __global__ void __launch_bounds__(512, 2) stem8_kernel(const StemParams p) {
 #undef ST8_PW
 
     // ---- (e) epilogue: strip i = MFMA row tile 2 wmr + i (output rows 4 wmr + 2 i, + 1), 16 pixels x 32 channels
-    {
+    if (p.abl & 8) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else {
       float b2v[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) b2v[j] = sB[192 + wnq * 32 + j * 16 + lrow];
@@ -652,26 +349,14 @@ __global__ void __launch_bounds__(512, 2) stem8_kernel(const StemParams p) {
 #undef ST8_DECODE
 }
 
-extern thread_local int g_conv_variant;   // conv_gemm.hip (cft_set_conv_variant): 8816 = the 8 x 16-tile, one-workgroup-per-CU form (A/B)
+extern thread_local int g_conv_variant;   // conv_gemm.hip (cft_set_conv_variant): 8800 + bits = timing probes (StemParams.abl)
 
 template <typename T, typename IN>
-static int launch_stem(const StemParams& p0, hipStream_t stream) {
-  int dev = 0, cus = 256;
+static int launch_stem(const StemParams& p0, hipStream_t stream) {   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   cus = cus > 8 ? (cus / 8) * 8 : 8;                     // a multiple of the 8 XCDs: a workgroup's tiles stay on its XCD
   StemParams p = p0;
-  if (g_conv_variant == 8816) {                           // 8 x 16 tiles, one persistent workgroup per CU (all of its LDS)
-    constexpr int smem_bytes = 36 * 16 * 128 + 4 * 16384 + 19 * 2 * 18 * 32 + 16 + 320 * 4;     // 162 448 B of the CU's 163 840
-    cft_allow_lds<&stem_kernel<T, IN>>(smem_bytes);
-    const int grid = p.ntiles < cus ? p.ntiles : cus;
-    hipLaunchKernelGGL((stem_kernel<T, IN>), dim3(grid), dim3(512), smem_bytes, stream, p);
-    return cft_check_launch("stem_kernel");
-  }
-  // 8 x 8 tiles, two persistent workgroups per CU
-  p.tiles_x = (p.Wo + 7) / 8; p.tiles_y = (p.Ho + 7) / 8;
-  const long nt = (long)(p.ntiles / (p0.tiles_x * p0.tiles_y)) * p.tiles_x * p.tiles_y;
-  if (nt >= (1L << 31)) { cft_set_error("cft_stem: too many tiles"); return CFT_EINVAL; }
-  p.ntiles = (int)nt;
+  p.abl = (g_conv_variant >= 8800 && g_conv_variant < 8864) ? g_conv_variant - 8800 : 0;
   constexpr int smem_bytes = 19 * 16 * 128 + 2 * 16384 + 16 + 320 * 4;                          // 72 976 B: two workgroups per CU
   cft_allow_lds<&stem8_kernel<T, IN>>(smem_bytes);
   const int grid = p.ntiles < 2 * cus ? p.ntiles : 2 * cus;
@@ -715,7 +400,7 @@ extern "C" int cft_stem(const void* in, int in_kind, long stride_b, long stride_
   p.y = (unsigned char*)y; p.ldy = ldy; p.yoff = yoff; p.N2 = n2; p.act2 = act2;
   p.Hf = H / 2; p.Wf = W / 2;
   p.Ho = (p.Hf - 1) / 2 + 1; p.Wo = (p.Wf - 1) / 2 + 1;          // 3x3, stride 2, padding 1
-  p.tiles_x = (p.Wo + 15) / 16; p.tiles_y = (p.Ho + 7) / 8;
+  p.tiles_x = (p.Wo + 7) / 8; p.tiles_y = (p.Ho + 7) / 8; p.abl = 0;
   CFT_REQUIRE((long)B * p.tiles_x * p.tiles_y < (1L << 31) && (long)B * p.Ho * p.Wo * ldy < (1L << 31), "cft_stem: tensor too large (split the batch)");
   p.ntiles = B * p.tiles_x * p.tiles_y;
   hipStream_t s = as_stream(stream);

@@ -359,7 +359,9 @@ class Model(nn.Module):
             self.__dict__.get("_graphs", {}).clear()
         return property(get, set_, doc=doc)
 
-    fuse_stem = _switch("fuse_stem", True, "Run Focus + the stride-2 Conv + the following C3's cv1|cv2 as one kernel where ops.stem_ok allows (yolov5l widths).")
+    fuse_stem = _switch("fuse_stem", False, "Opt-in: run Focus + the stride-2 Conv + the following C3's cv1|cv2 as ONE kernel (ops.stem, yolov5l widths). Bit-identical; "
+                        "-7 % HBM traffic per forward (the 839-MB Focus tensor per stream never exists) but no time: 943 us per launch against 313 + 463 us, "
+                        "-1 % pairs/s (profiles/r05_stem.md) - hence off by default.")
     fuse_cft_outputs = _switch("fuse_cft_outputs", True, "Run the two Add2 layers behind a GPT block and the Add that sums them as one kernel (cft_fusion_plan).")
     plan_concats = _switch("plan_concats", True, "Let Conv / C3 / Add layers that feed a head Concat write straight into their slice of its buffer (concat_plan).")
     depth_first = _switch("depth_first", None,

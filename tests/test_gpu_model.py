@@ -511,6 +511,7 @@ def test_conv_c3_chain_is_bit_identical_to_the_layerwise_walk(dev, dtype):
     from msod_amd.utils.seeded import seeded_inputs
     cfg, model, sd = _seeded("cfg3", 3)
     model = model.to(dev).set_compute_dtype(dtype)
+    model.fuse_stem = True                           # opt-in (default off: no faster than its two kernels, profiles/r05_stem.md)
     assert model.chain_plan() == frozenset({1, 3, 6, 8, 13, 15})
     rgb, ir = seeded_inputs(2, 192, 256, 3)
     x, x2 = rgb.to(dev), ir.to(dev)

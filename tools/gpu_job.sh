@@ -90,13 +90,11 @@ PY
     timeout 1500 python -m pytest tests/test_gpu_model.py tests/test_gpu_ops.py -q -m gpu -x -k "stem or chain or focus or depth_first or graph_replay or uint8 or six_channel" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -5 $O/tests.log
     X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
     run() { tag=$1; shift; timeout 400 python bench.py $X "$@" > $O/b.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/b.json'));r=d['roofline'];print('$tag', d['value'], d['ms_per_step'], (d.get('single_in_flight') or {}).get('value'), r['whole_step']['frac'], r['floors']['algorithmic_gbytes_per_step'], d['config'].get('stream_group_probe_ms_per_step'))" | tee -a $O/summary.txt; }
-    run "default (stem 8x8, two workgroups per CU)"; cp gpurun_out/bench_families.json $O/families_default.json
-    run "no stem" --no-stem; cp gpurun_out/bench_families.json $O/families_nostem.json
-    run "stem 8x16, one workgroup per CU" --conv-variant 8816; cp gpurun_out/bench_families.json $O/families_stem16.json
-    run "default (stem 8x8, two workgroups per CU)"
-    run "no stem" --no-stem
-    run "bs8 default" --batch 8
-    run "bs8 no stem" --batch 8 --no-stem ;;
+    run "stem" --stem; cp gpurun_out/bench_families.json $O/families_stem.json
+    run "default (Focus, then chained Conv + C3)"; cp gpurun_out/bench_families.json $O/families_default.json
+    run "stem" --stem
+    run "default (Focus, then chained Conv + C3)"
+    timeout 300 python tools/stem_bench.py > $O/stem_bench.txt 2>&1; cat $O/stem_bench.txt ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
