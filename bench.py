@@ -100,7 +100,7 @@ def traffic_from_profile(args, n_launch, abytes):
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh ->
     profiles/*_traffic.json: FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, summed
     over the conv_gemm family of one forward).  Only reported for the configuration it was collected on."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (4, 3, 2, 1)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(q)), None)
     if path is None:
         return None
     t = json.load(open(path))
@@ -475,12 +475,24 @@ def main():
         if cft_ms > 0:
             cft_bytes = sum(v[3] for k, v in fam.items() if k.startswith("linear")) + sum(v[3] for v in aux.values())
             cft_mfma_ms, cft_hbm_ms = cft_flops / (peak * 1e12) * 1e3, cft_bytes / (HBM_ACHIEVABLE_TBPS * 1e12) * 1e3
+            # The block's TRUE minimum traffic: its feature maps in (tokeniser), the bases re-read and the three maps
+            # written by the output stage, and every linear's weights once - what an implementation that keeps tokens / QKV / hidden layers
+            # on chip would move.  The per-kernel figure (every kernel's inputs + outputs once) is kept as hbm_ms_per_kernel_tensors.
+            import re as _re
+            es_ = 4 if dtype == torch.float32 else 2
+            w_bytes = sum(v[0] * int(m_.group(1)) * int(m_.group(2)) * es_ for k, v in fam.items() if k.startswith("linear")
+                          for m_ in [_re.match(r"linear_k1s1_n(\d+)_K(\d+)", k)] if m_)
+            io_bytes = sum(v[3] for k, v in aux.items() if k in ("cft_tokenize", "cft_upsample_add"))
+            blk_min_ms = (w_bytes + io_bytes) / (HBM_ACHIEVABLE_TBPS * 1e12) * 1e3
             cft_block = {"tflops": round(cft_flops / cft_ms / 1e9, 1), "frac": round(cft_flops / cft_ms / 1e9 / peak, 4), "ms": round(cft_ms, 3),
-                         # what the block's own FLOPs and bytes allow: with 128 tokens per image the attention core has 64 FLOP per byte and the
-                         # d = 256 / 512 linears 150 - 400, against a machine balance of ~400 FLOP/B - most of the block is HBM-bound by roofline
-                         "floors": {"mfma_ms": round(cft_mfma_ms, 3), "hbm_ms_algorithmic": round(cft_hbm_ms, 3),
-                                    "max_frac_of_mfma_peak_if_both_overlap_perfectly": round(cft_mfma_ms / max(cft_mfma_ms, cft_hbm_ms), 4),
-                                    "max_frac_if_they_add": round(cft_mfma_ms / (cft_mfma_ms + cft_hbm_ms), 4)},
+                         "floors": {"mfma_ms": round(cft_mfma_ms, 3),
+                                    "hbm_ms_block_minimum": round(blk_min_ms, 3), "block_minimum_gbytes": round((w_bytes + io_bytes) / 1e9, 3),
+                                    "hbm_ms_per_kernel_tensors": round(cft_hbm_ms, 3),
+                                    "bound_by_roofline": "mfma" if cft_mfma_ms >= blk_min_ms else "hbm",
+                                    "note": "block minimum = feature maps in + bases re-read + three maps out + weights once (tokens, QKV, hidden layers on chip); "
+                                            "per_kernel_tensors = every launched kernel's inputs once + outputs once (what this decomposition moves at best)",
+                                    "max_frac_of_mfma_peak_with_this_decomposition_if_mfma_and_hbm_overlap": round(cft_mfma_ms / max(cft_mfma_ms, cft_hbm_ms), 4),
+                                    "max_frac_with_this_decomposition_if_they_add": round(cft_mfma_ms / (cft_mfma_ms + cft_hbm_ms), 4)},
                          "launches": sum(v[0] for k, v in fam.items() if k.startswith("linear")) + sum(v[0] for v in aux.values()),
                          "parts_ms": {"linears": lin["ms"], **{k[4:]: round(v[2] * 1e3, 3) for k, v in aux.items()}}}
         line = {

@@ -12,7 +12,7 @@ case $JOB in
     timeout 900 python bench.py > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee -a $O/summary.txt
     tail -3 $O/bench.log; head -c 600 $O/bench.json ;;
   tests)       # full -m gpu suite + smoke
-    timeout 2400 python -m pytest tests -q -m gpu -x "$@" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt
+    timeout 2400 python -m pytest tests -q -m gpu -x --durations=40 "$@" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt
     tail -5 $O/tests.log
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/summary.txt; tail -3 $O/smoke.log ;;
   gemm)        # tools/gemm_bench.py A/B: gpu_job.sh gemm <variants> [only-filter]
