@@ -103,6 +103,7 @@ def _forward(cfg, sd, rgb, ir, q0, res32=False, sites=None, layer_filter=None, s
 
     layers, save = build_graph(cfg)
     y = []
+    unrounded = {}          # Add2 outputs before their storage rounding (see "Add" below)
     x = rgb
     for L in layers:
         i, f, t = L["i"], L["f"], L["type"]
@@ -129,9 +130,16 @@ def _forward(cfg, sd, rgb, ir, q0, res32=False, sites=None, layer_filter=None, s
         elif t == "Concat":
             x = torch.cat(xin, 1)
         elif t == "Add":
-            x = q(xin[0] + xin[1], "add")
+            # The product's CFT output stage (cft_gpt_upsample_add2) forms the Add of two Add2 outputs from their UNROUNDED fp32 sums and
+            # rounds once; an Add of anything else sums the stored (rounded) tensors.
+            srcs = [i - 1 if j == -1 else j for j in f] if not isinstance(f, int) else []
+            if len(srcs) == 2 and all(j in unrounded for j in srcs):
+                x = q(unrounded[srcs[0]] + unrounded[srcs[1]], "add")
+            else:
+                x = q(xin[0] + xin[1], "add")
         elif t == "Add2":
-            x = q(xin[0] + xin[1][L["index"]], "add2")
+            unrounded[i] = xin[0] + xin[1][L["index"]]
+            x = q(unrounded[i], "add2")
         elif t == "GPT":
             x = gpt(p, xin[0], xin[1])
         elif t == "nn.Upsample":

@@ -41,6 +41,22 @@ BF16_LOGIT_RMS = 3e-2
 BF16_RMS_RATIO, BF16_MAX_RATIO = 1.25, 1.75   # HIP bf16 error vs the error of the bf16-storage model of the oracle
 
 
+_ORACLE_CACHE = {}
+
+
+def _oracle_for(path, kind="fp32"):
+    """The CPU oracle's (pred, raw) for a golden case, computed once per session and kind ("fp32" = OracleModel, "lowp_bf16" = the bf16
+    storage model): the three precision tests of a case share it (the CPU work dominates the suite's wall time)."""
+    key = (path, kind)
+    if key not in _ORACLE_CACHE:
+        from oracle.cft_oracle import OracleModel
+        from oracle.lowp_oracle import LowpOracle
+        g, cfg, model, rgb, ir = load_case(path)
+        sd = model.state_dict()
+        _ORACLE_CACHE[key] = OracleModel(cfg)(sd, rgb, ir) if kind == "fp32" else LowpOracle(cfg, torch.bfloat16)(sd, rgb, ir)
+    return _ORACLE_CACHE[key]
+
+
 def _run(model, rgb, ir, dev, dtype):
     model = model.to(dev).set_compute_dtype(dtype)
     with torch.no_grad():
@@ -88,9 +104,8 @@ def _check_bf16(pred, raw, want_pred, want_raw, lowp_raw=None):
 # ------------------------------------------------------------------------- golden shapes, every config
 @pytest.mark.parametrize("path", GOLDEN, ids=IDS)
 def test_fp32_matches_oracle_and_golden(dev, path):
-    from oracle.cft_oracle import OracleModel
     g, cfg, model, rgb, ir = load_case(path)
-    want_pred, want_raw = OracleModel(cfg)(model.state_dict(), rgb, ir)
+    want_pred, want_raw = _oracle_for(path)
     pred, raw = _run(model, rgb, ir, dev, torch.float32)
     _check_fp32(pred, raw, want_pred, want_raw)
     _check_fp32(pred, raw, g["pred"], g["raw"])            # and against the reference's own output
@@ -98,9 +113,8 @@ def test_fp32_matches_oracle_and_golden(dev, path):
 
 @pytest.mark.parametrize("path", GOLDEN, ids=IDS)
 def test_f16_matches_oracle_within_1e2(dev, path):
-    from oracle.cft_oracle import OracleModel
     g, cfg, model, rgb, ir = load_case(path)
-    want_pred, want_raw = OracleModel(cfg)(model.state_dict(), rgb, ir)
+    want_pred, want_raw = _oracle_for(path)
     pred, raw = _run(model, rgb, ir, dev, torch.float16)
     _check_f16(pred, raw, want_pred, want_raw)
     _check_f16(pred, raw, g["pred"], g["raw"])
@@ -108,12 +122,9 @@ def test_f16_matches_oracle_within_1e2(dev, path):
 
 @pytest.mark.parametrize("path", GOLDEN, ids=IDS)
 def test_bf16_matches_its_storage_model_and_oracle(dev, path):
-    from oracle.cft_oracle import OracleModel
-    from oracle.lowp_oracle import LowpOracle
     g, cfg, model, rgb, ir = load_case(path)
-    sd = model.state_dict()
-    want_pred, want_raw = OracleModel(cfg)(sd, rgb, ir)
-    _, lowp_raw = LowpOracle(cfg, torch.bfloat16)(sd, rgb, ir)
+    want_pred, want_raw = _oracle_for(path)
+    _, lowp_raw = _oracle_for(path, "lowp_bf16")
     pred, raw = _run(model, rgb, ir, dev, torch.bfloat16)
     _check_bf16(pred, raw, want_pred, want_raw, lowp_raw)
 

@@ -108,6 +108,11 @@ PY
     cp $(ls $O/prof1/*/*kernel_stats.csv | head -1) $O/bench_bs64_kernel_stats.csv; rm -rf $O/prof1
     timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof2 --output-format csv -- python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity > $O/prof2.log 2>&1; echo "prof two-stream rc=$?" | tee -a $O/summary.txt
     cp $(ls $O/prof2/*/*kernel_stats.csv | head -1) $O/bench_bs64_kernel_stats_two_streams_40steps.csv; rm -rf $O/prof2
+    # the parity-green 16-bit mode with the same evidence as the bf16 line: full line + rocprofv3 kernel stats
+    timeout 900 python bench.py --dtype f16 --no-cpu-baseline > $O/bench_bs64_f16.json 2> $O/bench_f16.log; echo "bench f16 rc=$?" | tee -a $O/summary.txt
+    cp gpurun_out/bench_families.json $O/gemm_families_cfg3_f16.json
+    timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof3 --output-format csv -- python bench.py --dtype f16 --steps 20 --warmup 3 --no-cpu-baseline --no-overlap --in-flight 1 --sustained-steps 0 --no-parity > $O/prof3.log 2>&1; echo "prof f16 single-stream rc=$?" | tee -a $O/summary.txt
+    cp $(ls $O/prof3/*/*kernel_stats.csv | head -1) $O/bench_bs64_f16_kernel_stats.csv; rm -rf $O/prof3
     head -c 1500 $O/bench_bs64.json ;;
   configs)     # bench lines of the other BASELINE configurations (single-GPU share)
     X="--no-cpu-baseline --no-f16-leg --sustained-steps 0"
