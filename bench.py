@@ -323,6 +323,8 @@ def main():
     ap.add_argument("--no-splitk", action="store_true", help="A/B: the CFT blocks' out_proj / fc2 as one launch each (round 4) instead of split-K + LayerNorm-reduce")
     ap.add_argument("--depth-first", default="", help="CHUNKS[,ROWS]: Model.depth_first - the image-only prefix of each backbone sub-batch by sub-batch "
                     "(Infinity-Cache residency); empty = layer by layer over the whole batch")
+    ap.add_argument("--stream-priorities", default="", help="A/B: HIP stream priority per forward in flight, e.g. -1,0 (ForwardPipeline.pick_streams(priorities=...); "
+                    "round 4 measured (-1, 0) and (-1, -1) slower than equal priorities, profiles/r04_forwards_in_flight.txt)")
     ap.add_argument("--conv-variant", type=int, default=0, help="A/B runs: cft_set_conv_variant() for the whole process (0 = automatic)")
     args = ap.parse_args()
 
@@ -385,7 +387,8 @@ def main():
         stream_probe_ms = None
         if k_fly > 1:
             runners = [(lambda c=c: c.replay_static()[0]) for c in caps]
-            fly_streams, stream_probe_ms = D.ForwardPipeline.pick_streams(runners, dev)      # untimed set-up: the stream group that overlaps best
+            prios = [int(v) for v in args.stream_priorities.split(",")] if args.stream_priorities else None
+            fly_streams, stream_probe_ms = D.ForwardPipeline.pick_streams(runners, dev, priorities=prios)      # untimed set-up: the stream group that overlaps best
             pipe = D.ForwardPipeline(runners, fly_streams, gather)
             step_fn = pipe.step
         else:
@@ -505,7 +508,7 @@ def main():
                        "pairs_per_gpu": args.batch, "image_size": args.size, "parallelism": f"batch-shard x{world}",
                        "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap, "forwards_in_flight": k_fly, "env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
                        **({"stream_group_probe_ms_per_step": stream_probe_ms} if stream_probe_ms else {}),
-                       **({"depth_first": args.depth_first} if args.depth_first else {}), **({"fuse_stem": True} if args.stem else {}),
+                       **({"depth_first": args.depth_first} if args.depth_first else {}), **({"fuse_stem": True} if args.stem else {}), **({"stream_priorities": args.stream_priorities} if args.stream_priorities else {}),
                        **({"conv_variant": args.conv_variant} if args.conv_variant else {})},
             "sustained": sustained, "single_in_flight": single, "multi_gpu_selfcheck": selfcheck,
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear family; incl. the dedicated Focus kernel and the fused 64- / 128-channel Bottleneck kernels: 2 + 27 launches of the cfg3 forward)",
