@@ -253,9 +253,19 @@ def conv2d_chain(x, pk1, pk2, act2, out=None):
     return out
 
 
-def conv2d_chain_res_ok(x, pk1, pk2):
-    """True when ``conv2d_chain_res`` takes the pair: ``conv2d_chain_ok`` and a 256-channel first layer (the four-image form of the kernel)."""
-    return pk1.n == 256 and conv2d_chain_ok(x, pk1, pk2)
+CHAIN_RES_MIN_ROWS = 192 * 256      # output pixels from which the chained kernel's 256-row tiles fill >= 3/4 of the 256 CUs
+
+
+def conv2d_chain_res_ok(x, pk1, pk2, any_size=False):
+    """True when ``conv2d_chain_res`` takes the pair: ``conv2d_chain_ok``, a 256-channel first layer (the four-image form of the kernel) and -
+    unless ``any_size`` - enough output pixels: the chained kernel exists in the 256 x 256 tile only, and below ~49 000 pixels (cfg3: < 32 pairs
+    at 640 x 640) the separate launches run on smaller tiles with 4 - 8 x the workgroups (measured at 8 pairs: 71 against ~33 us per pair of
+    launches, profiles/r05_splitk_ab.md)."""
+    if not (pk1.n == 256 and conv2d_chain_ok(x, pk1, pk2)):
+        return False
+    p_ = pk1.k // 2
+    rows = x.shape[0] * ((x.shape[2] + 2 * p_ - pk1.k) // pk1.s + 1) * ((x.shape[3] + 2 * p_ - pk1.k) // pk1.s + 1)
+    return any_size or rows >= CHAIN_RES_MIN_ROWS
 
 
 def conv2d_chain_res(x, pk1, res, pk2, act2, out1=None, out2=None):
@@ -263,7 +273,7 @@ def conv2d_chain_res(x, pk1, res, pk2, act2, out1=None, out2=None):
     and Bottleneck j+1's 1x1 conv inside a C3 with shortcuts.  Bit-identical to ``conv2d(x, pk1, SILU, residual=res)`` followed by
     ``conv2d(y1, pk2, act2)``; y1 is stored but never re-read, and the 1x1 launch disappears."""
     _require_cuda(x, "conv2d_chain_res")
-    if not conv2d_chain_res_ok(x, pk1, pk2):
+    if not conv2d_chain_res_ok(x, pk1, pk2, any_size=True):
         raise ValueError("conv2d_chain_res: layer pair not eligible (conv2d_chain_res_ok)")
     x, ldx = as_nhwc(x)
     B, C, H, W = x.shape
@@ -370,7 +380,7 @@ SPLITK_MAX_ROWS = 2048      # token rows (B * 128) up to which split-K pays: <= 
 
 def splitk_choice(rows, pk, dtype):
     """Number of K splits for ``linear_splitk`` (1 = run ``linear``): GEMMs whose 256 x 256 tiles would leave most of the 256 CUs idle and
-    whose K loop is long enough to cut (the CFT block's out_proj / fc2 at B * 128 rows) - the smallest of 2 / 4 / 8 that yields >= 192
+    whose K loop is long enough to cut (the CFT block's out_proj / fc2 at B * 128 rows) - the smallest of 2 / 4 / 8 that yields >= 128
     workgroups, each split keeping >= 4 K steps."""
     bk = 32 if dtype == torch.float32 else 64
     if pk.k != 1 or pk.kpad != pk.cin or pk.cin % bk or 2 * pk.kpad * (4 if dtype == torch.float32 else 2) + 128 > 65536:
@@ -387,7 +397,7 @@ def splitk_choice(rows, pk, dtype):
         if steps % s or steps // s < 4 or s * rows * pk.n >= 2 ** 31:
             break
         best = s
-        if t256 * s >= 192:
+        if t256 * s >= 128:      # half the CUs busy is enough: every further split doubles the partial sums the LayerNorm has to fold
             break
     return best
 

@@ -527,28 +527,33 @@ def test_conv_c3_chain_is_bit_identical_to_the_layerwise_walk(dev, dtype):
     rgb, ir = seeded_inputs(2, 192, 256, 3)
     x, x2 = rgb.to(dev), ir.to(dev)
     log = []
-    with torch.no_grad():
-        ops.set_launch_log(log)
-        try:
-            model.overlap_streams = False
-            pred_c, raw_c = model.forward_once(x, x2)
-        finally:
-            ops.set_launch_log(None)
-        model.overlap_streams = True
-        pred_c2, _ = model.forward_once(x, x2)
-        model.chain_convs = False
-        pred_u, raw_u = model.forward_once(x, x2)
-        model.chain_convs = True
-        model.fuse_stem = False                      # Focus on its own, the chains stay
-        pred_ns, _ = model.forward_once(x, x2)
-        model.fuse_stem = True
-        pred_u8 = model.forward_once((x * 255).round().to(torch.uint8), (x2 * 255).round().to(torch.uint8))[0]      # uint8 images through the stem
-        model.fuse_stem = False
-        pred_u8_ns = model.forward_once((x * 255).round().to(torch.uint8), (x2 * 255).round().to(torch.uint8))[0]
-        model.fuse_stem = True
-        model.capture(2, 192, 256)
-        pred_g = model(x, x2)[0].clone()
-    torch.cuda.synchronize()
+    monkey_rows = ops.CHAIN_RES_MIN_ROWS
+    ops.CHAIN_RES_MIN_ROWS = 0                       # (a 2-pair test: take the chained 3x3 + shortcut + 1x1 kernel regardless of the size heuristic)
+    try:
+        with torch.no_grad():
+            ops.set_launch_log(log)
+            try:
+                model.overlap_streams = False
+                pred_c, raw_c = model.forward_once(x, x2)
+            finally:
+                ops.set_launch_log(None)
+            model.overlap_streams = True
+            pred_c2, _ = model.forward_once(x, x2)
+            model.chain_convs = False
+            pred_u, raw_u = model.forward_once(x, x2)
+            model.chain_convs = True
+            model.fuse_stem = False                      # Focus on its own, the chains stay
+            pred_ns, _ = model.forward_once(x, x2)
+            model.fuse_stem = True
+            pred_u8 = model.forward_once((x * 255).round().to(torch.uint8), (x2 * 255).round().to(torch.uint8))[0]      # uint8 images through the stem
+            model.fuse_stem = False
+            pred_u8_ns = model.forward_once((x * 255).round().to(torch.uint8), (x2 * 255).round().to(torch.uint8))[0]
+            model.fuse_stem = True
+            model.capture(2, 192, 256)
+            pred_g = model(x, x2)[0].clone()
+        torch.cuda.synchronize()
+    finally:
+        ops.CHAIN_RES_MIN_ROWS = monkey_rows
     # rows 1-2, 3-4 (RGB), 6-7, 8-9 (IR); and inside the two 256-channel C3s of the head (no shortcuts) cv2[j] + cv1[j + 1], j = 0, 1
     # rows 0-2 / 5-7: Focus + Conv + cv1|cv2 as the one-kernel stem; rows 3-4 / 8-9: Conv + cv1|cv2 chained
     assert sum(1 for rec in log if rec[0].startswith("conv_stem")) == 2 and not any(rec[0].startswith("conv_focus") for rec in log)

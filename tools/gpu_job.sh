@@ -95,6 +95,18 @@ PY
     run "stem" --stem
     run "default (Focus, then chained Conv + C3)"
     timeout 300 python tools/stem_bench.py > $O/stem_bench.txt 2>&1; cat $O/stem_bench.txt ;;
+  r5d)         # round 5: small-batch regime after the size heuristics (chained 3x3 + shortcut only from 192 tiles; split-K to >= 128 workgroups)
+    timeout 600 python -m pytest tests/test_gpu_model.py tests/test_gpu_ops.py -q -m gpu -x -k "chain_res or c3_chain or splitk" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -3 $O/tests.log
+    X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
+    run() { tag=$1; shift; timeout 400 python bench.py $X "$@" > $O/b.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/b.json'));r=d['roofline'];print('$tag', d['value'], d['ms_per_step'], (d.get('single_in_flight') or {}).get('value'), r['whole_step']['frac'], r['by_block']['cft_block_whole']['ms'], r['by_block']['cft_block_whole']['frac'], r['by_block']['backbone_head_convs']['ms'])" | tee -a $O/summary.txt; }
+    run "bs8" --batch 8
+    run "bs8 no splitk" --batch 8 --no-splitk
+    run "bs8 no chain" --batch 8 --no-conv-chain
+    run "bs8" --batch 8
+    run "bs16" --batch 16
+    run "bs16 no splitk" --batch 16 --no-splitk
+    run "cfg5 16 pairs 1280" --config cfg5 --batch 16 --size 1280
+    run "cfg5 16 pairs 1280 no splitk" --config cfg5 --batch 16 --size 1280 --no-splitk ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
