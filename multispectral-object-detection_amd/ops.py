@@ -375,7 +375,9 @@ def linear(x, pk, act=ACT_NONE, residual=None, out=None, out_dtype=None):
     return out
 
 
-SPLITK_MAX_ROWS = 2048      # token rows (B * 128) up to which split-K pays: <= 16 pairs per GPU (BASELINE config 5's per-rank regime, small batches)
+SPLITK_MAX_ROWS = 1024      # token rows (B * 128) up to which split-K pays with two forwards in flight: <= 8 pairs per GPU.  At 2 048 rows it still buys
+                            # +4.8 % with ONE forward in flight (latency) but costs 0.6 - 2.6 % of the throughput with two (profiles/r05_splitk_ab.md): a
+                            # latency-bound deployment raises this constant
 
 
 def splitk_choice(rows, pk, dtype):
@@ -389,7 +391,7 @@ def splitk_choice(rows, pk, dtype):
     t256 = -(-rows // 256) * -(-pk.n // 256)
     # Measured (profiles/r05_splitk_ab.md): at 8192 rows (64 pairs) the split GEMMs gain 0.31 ms per forward and the LayerNorms that fold
     # 2-4 x [rows, d] fp32 partial sums lose 0.50 ms (HBM bytes); at 1024 rows (8 pairs) everything is latency-bound and the CFT block drops
-    # from 2.37 to 1.84 ms.  So: only where the un-split GEMM leaves >= 3/4 of the chip idle.
+    # from 2.37 to 1.84 ms.  So: only where the un-split GEMM leaves >= 3/4 of the chip idle, and only for small row counts (SPLITK_MAX_ROWS).
     if t256 >= 64 or rows > SPLITK_MAX_ROWS:
         return 1
     best = 1
