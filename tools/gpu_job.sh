@@ -107,6 +107,16 @@ PY
     run "bs16 no splitk" --batch 16 --no-splitk
     run "cfg5 16 pairs 1280" --config cfg5 --batch 16 --size 1280
     run "cfg5 16 pairs 1280 no splitk" --config cfg5 --batch 16 --size 1280 --no-splitk ;;
+  knobs)       # runtime-environment knobs on the default step (each leg in its own process; a crash only loses its leg)
+    X="--no-cpu-baseline --no-f16-leg --sustained-steps 0 --no-parity"
+    run() { tag=$1; shift; timeout 300 env "$@" python bench.py $X > $O/b.json 2>> $O/bench.log; rc=$?; python -c "import json;d=json.load(open('$O/b.json'));print('$tag', d['value'], d['ms_per_step'], (d.get('single_in_flight') or {}).get('value'), d['config'].get('stream_group_probe_ms_per_step'))" 2>/dev/null | tee -a $O/summary.txt || echo "$tag FAILED rc=$rc" | tee -a $O/summary.txt; rm -f $O/b.json; }
+    run "default" A=1
+    run "DEBUG_CLR_GRAPH_PACKET_CAPTURE=1" DEBUG_CLR_GRAPH_PACKET_CAPTURE=1
+    run "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0" DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
+    run "GPU_MAX_HW_QUEUES=2" GPU_MAX_HW_QUEUES=2
+    run "GPU_MAX_HW_QUEUES=6" GPU_MAX_HW_QUEUES=6
+    run "HSA_ENABLE_SDMA=0" HSA_ENABLE_SDMA=0
+    run "default" A=1 ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
