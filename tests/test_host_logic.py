@@ -369,3 +369,38 @@ def test_cft_fusion_plan_and_nms_module_structure():
     w = m.autoshape()
     assert isinstance(w, autoShape) and w.autoshape() is w and w.names == m.names and torch.equal(w.stride, m.stride)
     m._print_biases()
+
+
+def test_prefix_segments_and_executor_switches():
+    """Model.prefix_segments (the image-only prefix of each backbone that Model.depth_first runs sub-batch by sub-batch): a Focus fed by x or
+    x2 followed by f == -1 Conv / C3 rows with exactly one reader, ending on a C3; every executor switch is a property whose setter drops
+    the captured graphs."""
+    from msod_amd.models.configs import named_config
+    from msod_amd.models.yolo_test import Model
+    m = Model(named_config("cfg3"))
+    assert m.prefix_segments() == [(0, 4), (5, 9)] and m.prefix_segments(3) == [(0, 2), (5, 7)] and m.prefix_segments(2) == []
+    assert Model(named_config("cfg1")).prefix_segments() == [(0, 4), (10, 14)]            # add-fusion: row 4 is also read by the Add
+    assert Model(named_config("yolov5l_fusion_transformer_FLIR")).prefix_segments() == [(0, 2), (3, 5)]   # 4-GPT layout: GPT after P2
+    assert (m.depth_first, m.fuse_stem, m.splitk, m.chain_convs, m.fuse_cft_outputs, m.plan_concats) == (None, False, True, True, True, True)
+    for name, value in (("depth_first", (8, None)), ("fuse_stem", True), ("splitk", False), ("chain_convs", False),
+                        ("fuse_cft_outputs", False), ("plan_concats", False)):
+        m._graphs["sentinel"] = object()
+        setattr(m, name, value)
+        assert getattr(m, name) == value and not m._graphs, name
+
+
+def test_splitk_choice_rule():
+    """ops.splitk_choice (host decision, measured in profiles/r05_splitk_ab.md): split only GEMMs on the uniform K walk whose 256 x 256 tiles
+    leave >= 3/4 of the chip idle, only up to SPLITK_MAX_ROWS token rows, to the smallest split that yields 128 workgroups with >= 4 K
+    steps each."""
+    import torch
+    from msod_amd import ops
+    pk = lambda n, k: ops.pack_conv(torch.zeros(n, k), None, torch.bfloat16)      # noqa: E731
+    assert ops.splitk_choice(8192, pk(1024, 4096), torch.bfloat16) == 1          # 64 pairs: never
+    assert ops.splitk_choice(2048, pk(1024, 4096), torch.bfloat16) == 1          # above SPLITK_MAX_ROWS
+    assert ops.splitk_choice(1024, pk(1024, 4096), torch.bfloat16) == 8          # 16 tiles -> 128 workgroups of 8 K steps
+    assert ops.splitk_choice(1024, pk(256, 1024), torch.bfloat16) == 4           # 4 K steps per split is the floor
+    assert ops.splitk_choice(1024, pk(256, 256), torch.bfloat16) == 1            # 4 K steps in all
+    assert ops.splitk_choice(1024, pk(4096, 1024), torch.bfloat16) == 1          # wide N: 64 tiles already
+    assert ops.splitk_choice(1024, pk(1024, 1000), torch.bfloat16) == 1          # K not on the uniform walk (padded)
+    assert ops.splitk_choice(512, pk(1024, 4096), torch.float32) == 8            # fp32: 32-wide K steps
