@@ -117,6 +117,11 @@ PY
     run "GPU_MAX_HW_QUEUES=6" GPU_MAX_HW_QUEUES=6
     run "HSA_ENABLE_SDMA=0" HSA_ENABLE_SDMA=0
     run "default" A=1 ;;
+  pmc5)        # round 5: per-pair timing + PMC counters of the chained 3x3 + shortcut + 1x1 kernel at the bench shape
+    timeout 300 python tools/chain_bench.py --res > $O/chain_res_pairs.txt 2>&1; cat $O/chain_res_pairs.txt
+    bash tools/pmc.sh $O/pmc -- python tools/chain_bench.py --res --iters 3 > $O/pmc.log 2>&1
+    python tools/pmc_summary.py $O/pmc conv_gemm > $O/pmc_chainres_3x3_256ch_40x40.txt; rm -rf $O/pmc
+    cat $O/pmc_chainres_3x3_256ch_40x40.txt | head -80 ;;
   bench)       # headline bench line (+ extra args)
     timeout 900 python bench.py "$@" > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/summary.txt
     tail -4 $O/bench.log; head -c 400 $O/bench.json ;;
