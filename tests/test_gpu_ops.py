@@ -750,7 +750,7 @@ def test_alternative_gemm_variants_are_bit_identical(dev, dtype, variant, case):
 
 @pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
 def test_probe_build_8wave_kernel_is_bit_identical(dev, dtype):
-    """The 8-wave register-double-buffered 256x256 kernel (csrc/conv_ring.hip, probe build only: it is slower than the shipped 16-wave
+    """The 8-wave register-double-buffered 256x256 kernel (csrc/probes/conv_ring.hip, probe build only: it is slower than the shipped 16-wave
     kernel, profiles/r04_gemm_experiments.md) against the generic path of the same library, bit for bit, on the eligible cases above
     plus a wide layer with two N tiles.  Skipped when libcft_hip_probes.so has not been built (tools/build_probes.sh)."""
     import os
