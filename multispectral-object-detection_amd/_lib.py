@@ -15,9 +15,9 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcft_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("runtime.hip", "conv_gemm.hip", "focus_conv.hip", "stem.hip", "bottleneck.hip", "pointwise.hip", "attention.hip", "nms.hip", "train.hip")
+SOURCES = ("runtime.hip", "conv_gemm.hip", "conv_gemm_asm.hip", "focus_conv.hip", "stem.hip", "bottleneck.hip", "pointwise.hip", "attention.hip", "nms.hip", "train.hip")
 
-HEADERS = ("cft_common.h", "conv_common.h", "focus_common.h")
+HEADERS = ("cft_common.h", "conv_common.h", "focus_common.h", "conv_gemm_asm.inc")
 
 CFT_BF16, CFT_F32, CFT_F16 = 0, 1, 2
 ABI_VERSION = 10

@@ -175,5 +175,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc
 }
 
 
+// conv_gemm_asm.hip: the 8-wave 256 x 256 kernel with the hand-scheduled K loop (16-bit operands, uniform K walk): eligibility and launch
+bool conv_asm_ok(const ConvParams& p, int dtype);
+int conv_asm_launch(const ConvParams& p, int dtype, hipStream_t stream);
+
 // conv_ring.hip: launch the ring kernel (dtype CFT_BF16 / CFT_F16; ablate: timing probes of -DCFT_PROBES builds, 0 otherwise)
 int conv_ring_launch(const ConvParams& p, int dtype, int ablate, hipStream_t stream);

@@ -515,8 +515,12 @@ static int launch_ring(const ConvParams& p, hipStream_t stream) {
 #endif
 
 template <typename T>
+static constexpr int dtype_code() { return sizeof(T) != 2 ? CFT_F32 : (__is_same(T, f16_t) ? CFT_F16 : CFT_BF16); }
+
+template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   switch (g_conv_variant) {
+    case 96: if (conv_asm_ok(p, dtype_code<T>())) return conv_asm_launch(p, dtype_code<T>(), stream); break;   // the hand-scheduled 8-wave kernel wherever eligible
     case 1: return launch_conv<T, 128, 128, 2, 2, false>(p, stream);   // register-staged baseline
     case 2: return launch_auto<T, 128, 128, 2, 2>(p, stream);
     case 4: return launch_auto<T, 128, 64, 2, 2>(p, stream);
@@ -589,6 +593,8 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
 #ifdef CFT_PROBES
     if (g_conv_variant == 90 && ring_ok<T>(p)) return launch_ring<T>(p, stream);    // A/B: the 8-wave kernel in place of the 16-wave 256x256 tile
 #endif
+    // the hand-scheduled 8-wave form of this tile (conv_gemm_asm.hip: bit-identical, K loop at 1.27 instead of 1.5 us per step); variant 97: the round-5 choice
+    if (g_conv_variant != 97 && conv_asm_ok(p, dtype_code<T>())) return conv_asm_launch(p, dtype_code<T>(), stream);
     return launch_auto<T, 256, 256, 4, 4>(p, stream);
   }
   if (wide_ok && tiles(128, 256) >= kCUs) return launch_auto<T, 128, 256, 4, 4>(p, stream);   // e.g. CFT fc2 at M = 8192

@@ -1,0 +1,304 @@
+// The wide layers' implicit-GEMM kernel with a HAND-SCHEDULED K loop (round 6): 256 x 256 tile, EIGHT waves (2 x 4) of 128 x 64,
+// the whole main loop ONE inline-asm statement written by tools/gen_conv_asm.py (conv_gemm_asm.inc; register map, schedule and
+// measurements in that file's header).  Same GEMM as conv_gemm_kernel<T, 256, 256, 4, 4, GLDS, 0, UNIK> (conv_gemm.hip) - the
+// reference's Conv.forward / nn.Linear (models/common.py:36-50, :511, :532-538) - with the same fetches, the same LDS image, the
+// same fragment reads and the same k order per accumulator: results are bit-identical to that kernel
+// (tests/test_gpu_ops.py::test_asm_gemm_kernel_is_bit_identical).  What differs is WHEN things are issued:
+//   * fragments are double-buffered in registers (2 x 12 ds_read_b128 per wave and K step, each read one half step ahead of its MFMAs);
+//   * a staging buffer is free once every wave has READ it (half a step before its second half is multiplied), so the requests of
+//     step t + 2 go out in the second half of step t, one request per four MFMAs, the two waves of a SIMD two MFMAs apart;
+//   * one s_barrier per K step, placed where every wave has 32 MFMAs queued behind it;
+//   * the K walk (tap / channel-chunk order, byte offsets, tap validity bit) is a TABLE in the kernel-argument segment, read with
+//     s_load_dwordx4 one step ahead: the loop has no address arithmetic beyond three VALU operations per masked request.
+// hipcc does not keep any of this when it is written in HIP (profiles/r04_gemm_experiments.md, csrc/probes/conv_ring.hip); in asm
+// the loop runs at 2 140-2 200 cycles per 256 x 256 x 64 step against the 2 048 the matrix pipe needs (profiles/r06_kloop_microbench.md).
+#include "conv_common.h"
+#include <utility>
+#include "conv_gemm_asm.inc"
+
+constexpr int ASM_MAXE = 236;                 // table entries: K steps (rounded up to even) + 3
+struct ConvAsmParams {
+  ConvParams p;
+  int npairs;                                 // K steps / 2 (an odd count is rounded up: the extra step stages zeros)
+  int masked;
+  uint32_t table[ASM_MAXE][4];                // per K step: {A byte offset of (tap, chunk) in the pixel neighbourhood, B byte offset in a weight row, 1 << tap, 0}
+};
+static_assert(sizeof(ConvAsmParams) <= 4096, "kernel-argument segment");
+
+#define CONV_ASM_CLOBBERS                                                                                                  \
+  "memory", "scc", "vcc", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",                                          \
+  "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31", \
+  "a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63", \
+  "a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95", \
+  "a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127", \
+  "v27","v28","v29","v30","v31",                                                                                           \
+  "v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63", \
+  "v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95", \
+  "v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127"
+
+#define CONV_ASM_STMT(text_)                                                                                               \
+  asm volatile(text_                                                                                                       \
+               : [toff] "+s"(toff), [cnt] "+s"(cnt), [m0s] "=&s"(m0s)                                                      \
+               : [voa0] "v"(voa[0]), [voa1] "v"(voa[1]), [voa2] "v"(voa[2]), [voa3] "v"(voa[3]),                           \
+                 [vob0] "v"(vob[0]), [vob1] "v"(vob[1]), [vob2] "v"(vob[2]), [vob3] "v"(vob[3]),                           \
+                 [am0] "v"(am[0]), [am1] "v"(am[1]), [am2] "v"(am[2]), [am3] "v"(am[3]), [voob] "v"(voob),                 \
+                 [ra0] "v"(ra[0]), [ra1] "v"(ra[1]), [rb0] "v"(rb[0]), [rb1] "v"(rb[1]),                                   \
+                 [srda] "s"(srdA), [srdb] "s"(srdB), [wb] "s"(wb), [tab] "s"(tab)                                          \
+               : CONV_ASM_CLOBBERS)
+
+template <int... Is, class F>
+__device__ __forceinline__ void asm_static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void asm_static_for(F&& f) { asm_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// The epilogue of conv_common.h (conv_epilogue_impl: wave-private 16-row fp32 strips in LDS, + bias, activation, + residual, one rounding,
+// coalesced 16-byte stores) for a 128 x 64 wave tile whose accumulators live in a[0:127]: strip i reads its four tiles right before use.
+template <typename TH, int ACT, bool OUT_F32>
+__device__ __forceinline__ void conv_epilogue_agpr(const ConvParams& p, unsigned char* smem, int m0, int n0, int wm, int wn, int wave, int lane, const float (&bias_v)[4]) {
+  constexpr int WM = 128, WN = 64, MT = 8, NT = 4;
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  constexpr int SLD = WN + 4;
+  float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SLD);
+  constexpr int VPRB = WN / 8, VPL = (16 * VPRB + 63) / 64, RDEPTH = 2;
+  gran_t rpre[OUT_F32 ? 1 : RDEPTH][OUT_F32 ? 1 : VPL];
+  const bool res_pre = !OUT_F32 && p.res != nullptr && !p.res_f32;   // uniform
+  auto res_fetch = [&](int strip) {
+#pragma unroll
+    for (int v_ = 0; v_ < VPL; ++v_) {
+      const int it_ = lane + v_ * 64;
+      const int row_ = it_ / VPRB, col_ = (it_ - row_ * VPRB) * 8;
+      const int m_ = m0 + wm * WM + strip * 16 + row_, n_ = n0 + wn * WN + col_;
+      gran_t t_ = {0u, 0u, 0u, 0u};
+      if (m_ < p.M && n_ < p.N) t_ = *reinterpret_cast<const gran_t*>(p.res + ((long)m_ * p.ldr + p.roff + n_) * 2);
+      rpre[strip % RDEPTH][v_] = t_;
+    }
+  };
+  if constexpr (!OUT_F32) {
+    if (res_pre) { res_fetch(0); res_fetch(1); }
+  }
+  asm_static_for<MT>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    asm_static_for<NT>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const f32x4_t t = agpr_tile<i * NT + j>();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) stage[(lgrp * 4 + e) * SLD + j * 16 + lrow] = apply_act<ACT>(t[e] + bias_v[j]);
+    });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int mbase = m0 + wm * WM + i * 16;
+    const int nbase = n0 + wn * WN;
+    if constexpr (OUT_F32) {
+      constexpr int VPR = WN / 4;
+      for (int it = lane; it < 16 * VPR; it += 64) {
+        const int row = it / VPR, col = (it - row * VPR) * 4;
+        const int m = mbase + row, n = nbase + col;
+        if (m < p.M && n < p.N) {
+          const f32x4_t sv = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col);
+          float v[4] = {sv[0], sv[1], sv[2], sv[3]};
+          if (p.res != nullptr) {
+            const long ro = (long)m * p.ldr + p.roff + n;
+            if (p.res_f32) {
+              const float4 rr = *reinterpret_cast<const float4*>(p.res + ro * 4);
+              v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+            } else {
+              const uint2 rr = *reinterpret_cast<const uint2*>(p.res + ro * 2);
+              float r0, r1, r2, r3;
+              Elem<TH>::unpack2(rr.x, r0, r1);
+              Elem<TH>::unpack2(rr.y, r2, r3);
+              v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+            }
+          }
+          *reinterpret_cast<f32x4_t*>(p.y + ((long)m * p.ldy + p.yoff + n) * 4) = f32x4_t{v[0], v[1], v[2], v[3]};
+        }
+      }
+    } else {
+      constexpr int VPR = WN / 8;
+#pragma unroll
+      for (int vi = 0; vi < VPL; ++vi) {
+        const int it = lane + vi * 64;
+        const int row = it / VPR, col = (it - row * VPR) * 8;
+        const int m = mbase + row, n = nbase + col;
+        if (m < p.M && n < p.N) {
+          const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col);
+          const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + row * SLD + col + 4);
+          float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+          if (res_pre) {
+            float rf[8];
+            Elem<TH>::unpack(rpre[i % RDEPTH][vi], rf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rf[e];
+          } else if (p.res != nullptr) {   // fp32 residual stream of the CFT block
+            const long ro = (long)m * p.ldr + p.roff + n;
+            const float4 r0v = *reinterpret_cast<const float4*>(p.res + ro * 4);
+            const float4 r1v = *reinterpret_cast<const float4*>(p.res + ro * 4 + 16);
+            v[0] += r0v.x; v[1] += r0v.y; v[2] += r0v.z; v[3] += r0v.w;
+            v[4] += r1v.x; v[5] += r1v.y; v[6] += r1v.z; v[7] += r1v.w;
+          }
+          *reinterpret_cast<gran_t*>(p.y + ((long)m * p.ldy + p.yoff + n) * 2) = Elem<TH>::pack(v);
+        }
+      }
+      if (res_pre && i + RDEPTH < MT) res_fetch(i + RDEPTH);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  });
+}
+
+template <typename T, bool MASKED>
+__global__ void __launch_bounds__(512) conv_gemm_asm_kernel(const ConvAsmParams ap) {
+  static_assert(sizeof(T) == 2, "16-bit operand types only");
+  constexpr int BM = 256, BN = 256, GE = 8, ES = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const ConvParams& p = ap.p;
+
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, slot = bid >> 3;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;      // consecutive tiles on one XCD (as conv_gemm_kernel)
+  const int tm = logical / p.tilesN, tn = logical - tm * p.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int rs = tid >> 3;                                             // staging row of this thread inside a 64-row pass
+  const int g = (tid & 7) ^ (rs & 7);                                  // k-granule it fetches (source-side swizzle: slot ^ (row & 7))
+
+  // Staging by buffer_load_dwordx4 ... lds: address = SRD base + per-thread voffset (constant) + SGPR offset from the K-walk table.  A masked
+  // granule (tap outside the image, row beyond M or N) is fetched at the out-of-range voffset 2^31: the load returns - the DMA writes - zeros.
+  // Only voffset is range-checked, so the input SRD starts `abias` bytes BELOW the tensor (the most negative tap of a border pixel) and every
+  // voffset carries + abias.
+  constexpr uint32_t OOB = 0x80000000u;
+  const long abias = ((long)p.W + 1) * p.ldx * ES;
+  uint32_t voa[4], vob[4], am[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + rs + i * 64;
+    int a_off = 0;
+    uint32_t mk = 0;
+    if (m < p.M) {
+      const int t = fast_div(m, p.wo_mul, p.wo_sh);
+      const int wo = m - t * p.Wo;
+      const int b = fast_div(t, p.ho_mul, p.ho_sh);
+      const int ho = t - b * p.Ho;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      a_off = ((b * p.H + hi0) * p.W + wi0) * p.ldx + p.xoff;
+      uint32_t wbits = 0;
+      for (int kw = 0; kw < p.KS; ++kw) wbits |= ((unsigned)(wi0 + kw) < (unsigned)p.W ? 1u : 0u) << kw;
+      for (int kh = 0; kh < p.KS; ++kh)
+        if ((unsigned)(hi0 + kh) < (unsigned)p.H) mk |= wbits << (kh * p.KS);
+    }
+    am[i] = mk;
+    voa[i] = (uint32_t)(((long)a_off + g * GE) * ES + abias);
+    if (!MASKED && mk == 0) voa[i] = OOB;                              // unmasked form (pointwise layers): only rows beyond M are masked, for good
+    const int n = n0 + rs + i * 64;
+    vob[i] = (n < p.N) ? (uint32_t)(((long)n * p.Kpad + g * GE) * ES) : OOB;
+  }
+  const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.x) - abias, 0, (int)(p.x_bytes + abias), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+  // fragment reads: lane l -> row l & 15 of a 16-row MFMA tile, k-granule (half * 4 + (l >> 4)) of the K step, in slot granule ^ (row & 7)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  // (LDS map: A images of even / odd steps at 0 / 32 KiB, B images at 64 / 96 KiB: the step parity goes into the instruction's offset field)
+  uint32_t ra[2], rb[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t rd = (uint32_t)(lrow * 128 + (((h * 4 + lgrp) ^ (lrow & 7)) << 4));
+    ra[h] = lds0 + wm * 16384u + rd;
+    rb[h] = lds0 + 65536u + wn * 8192u + rd;
+  }
+  float bias_v[4];
+  conv_load_bias<64>(p, n0, wn, lane, bias_v);
+
+  const uint32_t wb = lds0 + (uint32_t)wave * 1024u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long tab = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ConvAsmParams, table);
+#else
+  const unsigned long long tab = 0;
+#endif
+  uint32_t toff = 0, cnt = (uint32_t)ap.npairs, m0s;
+  const uint32_t voob = OOB;
+  if (wm == 0) {
+    if constexpr (__is_same(T, f16_t)) { if constexpr (MASKED) { CONV_ASM_STMT(CONV_ASM_LOOP_F16_MASK_G0); } else { CONV_ASM_STMT(CONV_ASM_LOOP_F16_NOMASK_G0); } }
+    else { if constexpr (MASKED) { CONV_ASM_STMT(CONV_ASM_LOOP_BF16_MASK_G0); } else { CONV_ASM_STMT(CONV_ASM_LOOP_BF16_NOMASK_G0); } }
+  } else {
+    if constexpr (__is_same(T, f16_t)) { if constexpr (MASKED) { CONV_ASM_STMT(CONV_ASM_LOOP_F16_MASK_G1); } else { CONV_ASM_STMT(CONV_ASM_LOOP_F16_NOMASK_G1); } }
+    else { if constexpr (MASKED) { CONV_ASM_STMT(CONV_ASM_LOOP_BF16_MASK_G1); } else { CONV_ASM_STMT(CONV_ASM_LOOP_BF16_NOMASK_G1); } }
+  }
+  // (the asm block ends with vmcnt(0) lgkmcnt(0): this wave's requests have landed, its reads returned; the strips alias the staging buffers)
+  __builtin_amdgcn_s_barrier();
+  // The epilogue's launch parameters are re-read from the kernel-argument segment HERE (the pointer is laundered through an empty asm so
+  // that the loads cannot be hoisted): held in SGPRs across the loop they would not fit beside the loop's own scalars.
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __attribute__((address_space(4))) ConvParams* kp = (const __attribute__((address_space(4))) ConvParams*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  const ConvParams pe = *kp;
+#else
+  const ConvParams& pe = p;
+#endif
+
+  if (pe.out_f32) {
+    if (pe.act == CFT_ACT_SILU) conv_epilogue_agpr<T, CFT_ACT_SILU, true>(pe, smem, m0, n0, wm, wn, wave, lane, bias_v);
+    else if (pe.act == CFT_ACT_GELU) conv_epilogue_agpr<T, CFT_ACT_GELU, true>(pe, smem, m0, n0, wm, wn, wave, lane, bias_v);
+    else conv_epilogue_agpr<T, CFT_ACT_NONE, true>(pe, smem, m0, n0, wm, wn, wave, lane, bias_v);
+  } else {
+    if (pe.act == CFT_ACT_SILU) conv_epilogue_agpr<T, CFT_ACT_SILU, false>(pe, smem, m0, n0, wm, wn, wave, lane, bias_v);
+    else if (pe.act == CFT_ACT_GELU) conv_epilogue_agpr<T, CFT_ACT_GELU, false>(pe, smem, m0, n0, wm, wn, wave, lane, bias_v);
+    else conv_epilogue_agpr<T, CFT_ACT_NONE, false>(pe, smem, m0, n0, wm, wn, wave, lane, bias_v);
+  }
+}
+
+// ------------------------------------------------------------------------------------ host
+// Eligibility: 16-bit operands, the uniform K walk (Cin a multiple of the 64-wide K step, no K padding), the walk fits the table, the
+// buffer-addressing extents (masked granules are fetched at voffset 2^31, so both buffers must end below it), no split-K.
+bool conv_asm_ok(const ConvParams& p, int dtype) {
+  if (dtype != CFT_BF16 && dtype != CFT_F16) return false;
+  if (p.Cin % 64 != 0 || p.Kpad != p.K || p.KS > 5 || p.ksplit > 1) return false;
+  const int nk = p.Kpad / 64;
+  if (nk < 2 || ((nk + 1) & ~1) + 3 > ASM_MAXE) return false;
+  return p.x_bytes + 2L * ((long)p.W + 1) * p.ldx * 2 < (1L << 31) && p.w_bytes < (1L << 31);
+}
+
+template <typename T, bool MASKED>
+static int launch_asm_t(const ConvAsmParams& ap, int grid, hipStream_t stream) {
+  constexpr int smem_bytes = 2 * (256 + 256) * 128;
+  cft_allow_lds<&conv_gemm_asm_kernel<T, MASKED>>(smem_bytes);
+  hipLaunchKernelGGL((conv_gemm_asm_kernel<T, MASKED>), dim3(grid), dim3(512), smem_bytes, stream, ap);
+  return cft_check_launch("conv_gemm_asm_kernel");
+}
+
+int conv_asm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
+  if (!conv_asm_ok(p, dtype)) { cft_set_error("conv_gemm_asm_kernel: layer not eligible"); return CFT_EINVAL; }
+  ConvAsmParams ap;
+  ap.p = p;
+  const int tilesM = (p.M + 255) / 256;
+  ap.p.tilesN = (p.N + 255) / 256;
+  ap.p.ksplit = 1;
+  const int nk = p.Kpad / 64, nkp = (nk + 1) & ~1;
+  ap.npairs = nkp / 2;
+  // K order: conv_gemm_kernel's - tap-major (k = (kh, kw, ci): the channel chunks of a tap, then the next tap), or CHUNK-major for 3x3 layers
+  // with Cin >= 256 (all nine taps of a 64-channel chunk, then the next chunk: a tap re-reads the pixels its neighbour just read)
+  const bool chunk_major = p.KS == 3 && p.Cin >= 256 && p.K == 9 * p.Cin;
+  const int chunks = p.Cin / 64, taps = p.KS * p.KS;
+  for (int t = 0; t < nkp + 3; ++t) {
+    uint32_t* e = ap.table[t];
+    if (t < nk) {
+      const int tap = chunk_major ? t % taps : t / chunks, chunk = chunk_major ? t / taps : t % chunks;
+      const int kh = tap / p.KS, kw = tap - kh * p.KS;
+      e[0] = (uint32_t)((((long)kh * p.W + kw) * p.ldx + chunk * 64) * 2);
+      e[1] = (uint32_t)(((long)tap * p.Cin + chunk * 64) * 2);
+      e[2] = 1u << tap;
+    } else {            // beyond K: the odd-count padding step stages zeros (tap bit 0 -> every A granule out of range); later entries are requested, never used
+      e[0] = 0; e[1] = 0; e[2] = 0;
+    }
+    e[3] = 0;
+  }
+  const bool masked = p.KS > 1 || (nk & 1);
+  ap.masked = masked;
+  const int grid = tilesM * ap.p.tilesN;
+  if (dtype == CFT_BF16) return masked ? launch_asm_t<uint16_t, true>(ap, grid, stream) : launch_asm_t<uint16_t, false>(ap, grid, stream);
+  return masked ? launch_asm_t<f16_t, true>(ap, grid, stream) : launch_asm_t<f16_t, false>(ap, grid, stream);
+}

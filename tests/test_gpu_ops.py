@@ -748,6 +748,77 @@ def test_alternative_gemm_variants_are_bit_identical(dev, dtype, variant, case):
         assert rel_err(got, ref) < tol(dtype)
 
 
+ASM_CASES = [
+    # B, H, W, Cin, Cout, k, s, residual      (the hand-scheduled 8-wave kernel takes 16-bit layers with Cin % 64 == 0)
+    (2, 24, 24, 256, 512, 3, 1, True),      # chunk-major walk (36 K steps), two N tiles, border taps on every side, ragged M (1152 rows = 4.5 tiles)
+    (1, 40, 40, 512, 256, 1, 1, False),     # pointwise: the unmasked form, 8 K steps
+    (2, 33, 31, 64, 320, 3, 1, True),       # tap-major walk with ONE chunk per tap (9 steps: odd -> the zero padding step), N tail, ragged M
+    (3, 20, 20, 128, 256, 3, 2, False),     # stride 2, tap-major with two chunks per tap
+    (1, 16, 16, 1024, 512, 1, 1, False),    # long pointwise K (16 steps)
+    (2, 9, 9, 512, 40, 3, 2, False),        # chunk-major, stride 2, N tail inside the first tile (72 steps)
+    (1, 20, 20, 320, 256, 1, 1, True),      # pointwise with an odd step count (5): the masked form with the zero step
+    (1, 7, 5, 128, 264, 1, 1, False),       # 35 rows: one ragged tile, two K steps (the shortest walk the kernel takes)
+]
+
+
+@pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", ASM_CASES, ids=[f"a{i}" for i in range(len(ASM_CASES))])
+def test_asm_gemm_kernel_is_bit_identical(dev, dtype, case):
+    """The 8-wave kernel with the hand-scheduled (inline-asm) K loop (csrc/conv_gemm_asm.hip, variant 96 = wherever eligible; the automatic
+    choice takes it for the wide layers) against the generic address path of the 16-wave kernel (variant 900): same fetches, same LDS image,
+    same k order per accumulator -> the same bits, with and without a shortcut, and close to torch's fp32 convolution."""
+    from msod_amd import _lib, ops
+    B, H, W, Cin, Cout, k, s_, use_res = case
+    x = _q(_rnd(B, Cin, H, W, seed=91), dtype)
+    w = _q(_rnd(Cout, Cin, k, k, seed=92, scale=1.0 / math.sqrt(Cin * k * k)), dtype)
+    b = _rnd(Cout, seed=93, scale=0.5)
+    pk = ops.pack_conv(w, b, dtype, s=s_, device=dev)
+    xd = to_dev_nhwc(x, dev, dtype)
+    lib = _lib.load()
+    outs = {}
+    for v in (900, 96):
+        lib.cft_set_conv_variant(v)
+        try:
+            y0 = ops.conv2d(xd, pk, 1)
+            res = y0.clone() if use_res else None
+            outs[v] = (y0, ops.conv2d(xd, pk, 1, residual=res))
+            torch.cuda.synchronize()
+        finally:
+            lib.cft_set_conv_variant(0)
+    for a, c in zip(outs[900], outs[96]):
+        assert torch.equal(a.float().cpu(), c.float().cpu())
+    ref = F.silu(F.conv2d(x, w, b, s_, k // 2))
+    assert rel_err(to_cpu_f32(outs[96][0])[:, :Cout], ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
+@pytest.mark.parametrize("rows,K,N", [(8192, 1024, 4096), (1000, 4096, 1024), (8192, 512, 512)])
+def test_asm_gemm_kernel_linear_forms(dev, dtype, rows, K, N):
+    """The nn.Linear forms the CFT block runs on the asm kernel (reference models/common.py:511, :532-538): GELU, fp32 output added to the fp32
+    residual stream, plain - bit-identical to the 16-wave kernel's generic path, many times over (a stale LDS tile would show as a flake)."""
+    from msod_amd import _lib, ops
+    x = _q(_rnd(rows, K, seed=5), dtype).to(dev).to(dtype)
+    w = _q(_rnd(N, K, seed=6, scale=1.0 / math.sqrt(K)), dtype)
+    pk = ops.pack_conv(w, _rnd(N, seed=7, scale=0.3), dtype, device=dev)
+    resid = _rnd(rows, N, seed=8).to(dev)
+    lib = _lib.load()
+    outs = {}
+    for v in (900, 96):
+        lib.cft_set_conv_variant(v)
+        try:
+            o = [ops.linear(x, pk, ops.ACT_GELU), ops.linear(x, pk, ops.ACT_NONE, residual=resid, out_dtype=torch.float32), ops.linear(x, pk)]
+            if v == 96:
+                o += [ops.linear(x, pk) for _ in range(20)]
+            torch.cuda.synchronize()
+            outs[v] = o
+        finally:
+            lib.cft_set_conv_variant(0)
+    for a, c in zip(outs[900], outs[96][:3]):
+        assert torch.equal(a.float().cpu(), c.float().cpu())
+    for c in outs[96][3:]:
+        assert torch.equal(c, outs[96][2])
+
+
 @pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
 def test_probe_build_8wave_kernel_is_bit_identical(dev, dtype):
     """The 8-wave register-double-buffered 256x256 kernel (csrc/probes/conv_ring.hip, probe build only: it is slower than the shipped 16-wave
