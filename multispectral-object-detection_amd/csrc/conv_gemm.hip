@@ -484,7 +484,11 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
   ConvParams q = p;
   const int tilesM = (p.M + BM - 1) / BM;
   q.tilesN = (p.N + BN - 1) / BN;
-  if (!UNIK || q.ksplit < 1) q.ksplit = 1;     // (split-K exists on the uniform K walk only; cft_linear_splitk checks eligibility first)
+  if (q.ksplit < 1) q.ksplit = 1;
+  if (!UNIK && q.ksplit > 1) {     // split-K exists on the uniform K walk only: parts[1..] would stay uninitialised
+    cft_set_error("conv_gemm_kernel: split-K needs the uniform-K-walk instantiation (this variant forces the generic address path)");
+    return CFT_EINVAL;
+  }
   hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WGM, WGN, GLDS, ABLATE, UNIK, CHAIN, CRES>), dim3(tilesM * q.tilesN * q.ksplit), dim3(64 * WGM * WGN), smem_bytes, stream, q);
   return cft_check_launch("conv_gemm_kernel");
 }
@@ -594,7 +598,8 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
     if (g_conv_variant == 90 && ring_ok<T>(p)) return launch_ring<T>(p, stream);    // A/B: the 8-wave kernel in place of the 16-wave 256x256 tile
 #endif
     // the hand-scheduled 8-wave form of this tile (conv_gemm_asm.hip: bit-identical, K loop at 1.27 instead of 1.5 us per step); variant 97: the round-5 choice
-    if (g_conv_variant != 97 && conv_asm_ok(p, dtype_code<T>())) return conv_asm_launch(p, dtype_code<T>(), stream);
+    // (taken from 12 K steps on: below that the 16-wave kernel's shorter prologue + epilogue outweigh the loop, profiles/r06_asm_kloop.md)
+    if (g_conv_variant != 97 && p.Kpad >= 12 * 64 && conv_asm_ok(p, dtype_code<T>())) return conv_asm_launch(p, dtype_code<T>(), stream);
     return launch_auto<T, 256, 256, 4, 4>(p, stream);
   }
   if (wide_ok && tiles(128, 256) >= kCUs) return launch_auto<T, 128, 256, 4, 4>(p, stream);   // e.g. CFT fc2 at M = 8192

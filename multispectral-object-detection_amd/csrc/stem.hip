@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(512, 2) stem8_kernel(const StemParams p) {
     ST8_STAGE(9) ST8_TAP(8) ST8_SYNC(0)                       // stage 9 (pointwise weights, k 0-63) landed; every wave is past its last F read
 #undef ST8_TAP
     ST8_STAGE(10)                                             // -> slot 0 (tap 8's readers are past the barrier)
+    __builtin_amdgcn_sched_barrier(0);                        // the counted waits below assume stage 10's two requests are OLDER than the image loads
     {   // the next tile's image samples: the youngest requests of the tile (the two waits below leave them in flight)
       const int vnext = vslot + gridDim.x;
       if (vnext < nt) {

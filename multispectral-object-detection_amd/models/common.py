@@ -324,14 +324,24 @@ class C3(_Packed):
         """Every Bottleneck has a shortcut and (cv2[j], cv1[j + 1]) is a pair ``ops.conv2d_chain_res`` takes on tensors shaped like ``y``."""
         if not (isinstance(y, torch.Tensor) and y.is_cuda and y.dtype in (torch.bfloat16, torch.float16)):
             return False
+        key = (tuple(y.shape), y.dtype, y.device)          # (the decision depends on the pixel grid and the type only: h and y1 are dense tensors of this shape)
+        cache = self.__dict__.setdefault("_res_chain_cache", {})
+        if key not in cache:
+            if len(cache) > 16:
+                cache.clear()
+            cache[key] = self._res_chainable_uncached(y)
+        return cache[key]
+
+    def _res_chainable_uncached(self, y):
         for j, blk in enumerate(self.m):
             if not blk.add or _act_code(blk.cv1.act) != ACT_SILU or _act_code(blk.cv2.act) != ACT_SILU:
                 return False
             pk1, pk2 = blk.cv1._packed(y.dtype, y.device), blk.cv2._packed(y.dtype, y.device)
             if ops.bottleneck_fusable(y, pk1, pk2, ACT_SILU, ACT_SILU):
                 return False               # 64 / 128 channels: the patch-resident Bottleneck kernel
-            if j + 1 < len(self.m) and not ops.conv2d_chain_res_ok(y, pk2, self.m[j + 1].cv1._packed(y.dtype, y.device)):
-                return False
+            if j + 1 < len(self.m) and not ops.conv2d_chain_res_ok_geometry(y.shape[0], y.shape[2], y.shape[3], y.dtype, pk2,
+                                                                            self.m[j + 1].cv1._packed(y.dtype, y.device)):
+                return False               # (dense h / y1 of this pixel grid - what the launch below passes; ADVICE r5)
         return True
 
     def _chainable(self, blk, nxt, y):

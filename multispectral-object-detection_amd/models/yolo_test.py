@@ -575,6 +575,9 @@ class Model(nn.Module):
         cbufs = {} if (x.is_cuda and self.plan_concats) else None   # planned concat buffers of this walk
         # depth-first prefix (Model.depth_first): {first row: (i0, i1)} and the rows a segment covers
         seg_at, seg_rows, df = {}, set(), self.depth_first
+        if df and self.fuse_stem:
+            raise ValueError("Model.depth_first and Model.fuse_stem exclude each other: a depth-first segment runs its Focus row on its own "
+                             "(the one-kernel stem would be silently skipped on the rows the segment covers)")
         if df and x.is_cuda and not self.training and not profile and cbufs is not None and x.shape[0] >= 2 * int(df[0]) > 0:
             for sg in self.prefix_segments(df[1] if len(df) > 1 else None):
                 seg_at[sg[0]] = sg

@@ -268,6 +268,16 @@ def conv2d_chain_res_ok(x, pk1, pk2, any_size=False):
     return any_size or rows >= CHAIN_RES_MIN_ROWS
 
 
+def conv2d_chain_res_ok_geometry(B, H, W, dtype, pk1, pk2, any_size=False):
+    """``conv2d_chain_res_ok`` for DENSE input / output tensors of the given pixel grid (what ``C3.forward`` passes: the hidden tensor and y1 are
+    dense; the shortcut's own row stride is checked at launch)."""
+    if not (pk1.n == 256 and conv2d_chain_ok_geometry(B, H, W, dtype, pk1, pk2)):
+        return False
+    p_ = pk1.k // 2
+    rows = B * ((H + 2 * p_ - pk1.k) // pk1.s + 1) * ((W + 2 * p_ - pk1.k) // pk1.s + 1)
+    return any_size or rows >= CHAIN_RES_MIN_ROWS
+
+
 def conv2d_chain_res(x, pk1, res, pk2, act2, out1=None, out2=None):
     """(y1, y2) = (SiLU(conv(x)) + res, act2(conv1x1(y1))) as ONE kernel (cft_conv2d_chain_res): Bottleneck j's 3x3 conv with its shortcut
     and Bottleneck j+1's 1x1 conv inside a C3 with shortcuts.  Bit-identical to ``conv2d(x, pk1, SILU, residual=res)`` followed by

@@ -31,7 +31,7 @@ from test_oracle_golden import load_case
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(__file__)
 GOLDEN = sorted(p for p in glob.glob(os.path.join(HERE, "golden", "*.pt"))
-                if not os.path.basename(p).startswith(("nms_", "ref_ckpt", "s_x3_train", "letterbox_", "lowp_", "survey_")))
+                if not os.path.basename(p).startswith(("nms_", "ref_ckpt", "s_x3_train", "letterbox_", "lowp_", "survey_", "ladder_")))
 IDS = [os.path.basename(p)[:-3] for p in GOLDEN]
 
 F16_SIGMOID_ATOL = 1e-2     # north_star's 16-bit bound, met in fp16 (measured <= 2e-3)
@@ -266,6 +266,74 @@ def test_survey_weights_meet_the_literal_bounds(dev, name):
     pred, raw = _run(model, rgb, ir, dev, torch.bfloat16)
     assert _sig_err(raw, rec["raw"]) <= 1e-2, f"bf16 sigmoid-space error {_sig_err(raw, rec['raw']):.3e}"
     assert (pred[..., 4:] - want_pred[..., 4:]).abs().max().item() <= 1e-2
+
+
+# ------------------------------------------------------------------------- the gain ladder: a bf16 bound that can fail
+from test_oracle_golden import _ladder_ref, ladder_case  # noqa: E402
+
+
+def _ladder_gains():
+    from msod_amd.utils.seeded import LADDER_GAINS
+    return list(LADDER_GAINS)
+
+
+@pytest.mark.parametrize("gain", _ladder_gains())
+def test_bf16_on_the_gain_ladder(dev, gain):
+    """cfg3 at 256 x 256 on every rung of the gain ladder (utils/seeded.ladder_state_dict), against the REFERENCE's recorded fp32 forward
+    (tests/golden/ladder_ref.pt).  On the rungs where the reference's own bf16-autocast forward meets north_star's 1e-2 (sigmoid space) AND
+    the output moves by >= 1e-2 rms when the images change - the bound can fail there for a kernel bug anywhere in the network - HIP bf16
+    is held to **1e-2 outright**; above (the stress weights), to 1.3 x the reference's own bf16 error; fp16 to 1e-2 on every rung, fp32 to 1e-3."""
+    from oracle.cft_oracle import OracleModel
+    rec, cfg, model, rgb, ir = ladder_case(gain)
+    want_pred, _ = OracleModel(cfg)(model.state_dict(), rgb, ir)
+    pred, raw = _run(model, rgb, ir, dev, torch.float32)
+    _check_fp32(pred, raw, want_pred, rec["raw"])
+    pred, raw = _run(model, rgb, ir, dev, torch.float16)
+    assert _sig_err(raw, rec["raw"]) <= 1e-2
+    pred, raw = _run(model, rgb, ir, dev, torch.bfloat16)
+    err = _sig_err(raw, rec["raw"])
+    if rec["sig_err_bf16"] <= 1e-2:
+        assert err <= 1e-2, f"gain {gain}: bf16 sigmoid-space error {err:.3e} (reference's own bf16: {rec['sig_err_bf16']:.3e}, input sensitivity {rec['sens_logit_rms']:.2e})"
+    else:
+        assert err <= 1.3 * rec["sig_err_bf16"], f"gain {gain}: bf16 error {err:.3e} vs the reference's own {rec['sig_err_bf16']:.3e}"
+    # ... and the HIP output itself moves with the images as the reference's does (a forward that ignored its input would pass a
+    # bound on insensitive weights): same second image pair as make_golden.py
+    from msod_amd.utils.seeded import seeded_inputs
+    c = rec["case"]
+    rgb2, ir2 = seeded_inputs(c["batch"], c["height"], c["width"], c["seed"] + 100)
+    _, raw2 = _run(model, rgb2, ir2, dev, torch.bfloat16)
+    moved = (_flat(raw2) - _flat(raw)).pow(2).mean().sqrt().item()
+    assert 0.7 * rec["sens_logit_rms"] - 2e-3 <= moved <= 1.3 * rec["sens_logit_rms"] + 2e-3
+
+
+def test_cfg3_ladder_rung_at_the_benchmarked_shape_bf16_within_1e2(dev):
+    """The benchmarked configuration (yolov5l + CFTx3, 640 x 640, BN folded, HIP-graph replay, bf16; 8 of the 64 pairs) on the HIGHEST
+    ladder rung whose reference-side bf16 error is below 1e-2 (gain 1.4 at 256 x 256: 8.9e-3, input sensitivity 4.2e-2 rms): **1e-2
+    asserted outright** against the fp32 oracle, which tests/test_oracle_golden.py pins to the reference on this rung."""
+    from msod_amd.models.configs import named_config
+    from msod_amd.models.yolo_test import Model
+    from msod_amd.utils.seeded import BENCH_LADDER_GAIN, ladder_state_dict, seeded_inputs
+    from oracle.cft_oracle import OracleModel
+    cfg = named_config("cfg3")
+    model = Model(cfg)
+    model.load_state_dict(ladder_state_dict(model.state_dict(), BENCH_LADDER_GAIN, 5))
+    model.fuse()
+    rgb, ir = seeded_inputs(8, 640, 640, 0)
+    idx = [0, 7]
+    want_pred, want_raw = OracleModel(cfg)(model.state_dict(), rgb[idx], ir[idx])
+    model = model.to(dev)
+    x, x2 = rgb.to(dev), ir.to(dev)
+    model.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        model.capture(8, 640, 640)
+        pred, raw = model(x, x2)
+        torch.cuda.synchronize()
+        pred, raw = pred[idx].cpu(), [r[idx].cpu() for r in raw]
+    model.release_graphs()
+    err = _sig_err(raw, want_raw)
+    assert err <= 1e-2, f"bf16 sigmoid-space error {err:.3e} at the bench shape on ladder rung {BENCH_LADDER_GAIN}"
+    moved = (_flat([r[:1] for r in want_raw]) - _flat([r[1:] for r in want_raw])).pow(2).mean().sqrt().item()
+    assert moved >= 1e-2           # pairs 0 and 7 differ by much more than the bound: the output depends on the images
 
 
 def test_cfg3_survey_weights_at_the_benchmarked_batch_of_64_bf16_within_1e2(dev):

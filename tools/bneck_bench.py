@@ -32,6 +32,8 @@ def timeit(fn, iters=20, repeats=3):
 
 def main():
     dev = torch.device("cuda:0")
+    if os.environ.get("CFT_BENCH_LIB"):          # e.g. the probe build (tools/build_probes.sh): libcft_hip_probes.so
+        _lib.LIB_PATH = os.path.abspath(os.environ["CFT_BENCH_LIB"])
     lib = _lib.load()
     g = torch.Generator().manual_seed(0)
     C = int(sys.argv[1]) if len(sys.argv) > 1 else 64

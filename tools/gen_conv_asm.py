@@ -111,9 +111,8 @@ def step(op, c, g, masked):
 
 def loop_text(op, g, masked):
     L = ["s_mov_b32 %[m0s], m0"]
-    for a in range(128):
-        L.append(f"v_accvgpr_write_b32 a{a}, 0")
-    # prologue: table entries 0 / 1 -> requests of steps 0 / 1; entry 2 -> quad 0; wait for step 0; read its k half 0
+    # prologue: table entries 0 / 1 -> requests of steps 0 / 1; entry 2 -> quad 0; (accumulators zeroed under the requests' flight;) wait
+    # for step 0; read its k half 0
     L += table_load(QUAD[0]) + table_load(QUAD[1]) + ["s_waitcnt lgkmcnt(0)"]
     for c in (0, 1):
         for m in mask_ops(QUAD[c], masked):
@@ -121,6 +120,8 @@ def loop_text(op, g, masked):
         for d in dmas(c, QUAD[c], masked):
             L += d
     L += table_load(QUAD[0])
+    for a in range(128):
+        L.append(f"v_accvgpr_write_b32 a{a}, 0")
     L += ["s_waitcnt vmcnt(8)", "s_barrier"]
     L += reads(0, 0)
     L += ["s_waitcnt lgkmcnt(0)"]
