@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libcft_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ("runtime.hip", "conv_gemm.hip", "conv_gemm_asm.hip", "focus_conv.hip", "stem.hip", "bottleneck.hip", "pointwise.hip", "attention.hip", "nms.hip", "train.hip")
 
-HEADERS = ("cft_common.h", "conv_common.h", "focus_common.h", "conv_gemm_asm.inc")
+HEADERS = ("cft_common.h", "conv_common.h", "focus_common.h", "bneck_common.h", "conv_gemm_asm.inc")
 
 CFT_BF16, CFT_F32, CFT_F16 = 0, 1, 2
 ABI_VERSION = 10

@@ -26,17 +26,7 @@ __device__ __attribute__((aligned(16))) uint32_t cft_zero_page_b[4] = {0u, 0u, 0
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-struct Bneck128Params {
-  const unsigned char* x;
-  const unsigned char* w1;   // [128][kpad1]
-  const unsigned char* w2;   // [128][kpad2], k = (kh*3 + kw)*128 + ci
-  const unsigned char* w2s;  // the same weights as 36 stage images of 8 KiB (cft_bottleneck_pack_w2), or null
-  const float* b1;
-  const float* b2;
-  unsigned char* y;
-  int ldx, xoff, ldy, yoff, kpad1, kpad2;
-  int H, W, tiles_x, tiles_y, ntiles, shortcut;
-};
+#include "bneck_common.h"
 
 // ------------------------------------------------------------------------------------ 128 channels
 // 80 x 80 maps, 21 Bottlenecks per yolov5l forward.  8 x 16-pixel tiles: t patch 10 x 18 pixels in two 64-channel planes
@@ -680,6 +670,13 @@ extern "C" int cft_bottleneck(const void* x, int ldx, int xoff, const void* w1, 
   }
 #endif
   if (c == 128) {
+#ifdef CFT_PROBES
+    if (g_conv_variant == 98 || (g_conv_variant >= 9300 && g_conv_variant < 9400)) {   // the 16 x 16-tile kernel with the hand-scheduled 3x3 loop (probes/bottleneck_asm.hip: slower, A/B only)
+      q.tiles_y = (H + 15) / 16;
+      q.ntiles = B * q.tiles_x * q.tiles_y;
+      return bneck128_asm_launch(q, dtype, s_);
+    }
+#endif
     if (dtype == CFT_F16) BNC_LAUNCH(f16_t, 0) else BNC_LAUNCH(uint16_t, 0)
     return cft_check_launch("bottleneck128c_kernel");
   }

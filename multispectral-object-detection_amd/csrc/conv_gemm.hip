@@ -475,6 +475,8 @@ extern "C" int cft_set_conv_variant(int v) {
   return old;
 }
 
+int cft_set_conv_variant_peek() { return g_conv_variant; }   // (bottleneck.hip: variant 97 = the round-5 kernels)
+
 template <typename T, int BM, int BN, int WGM, int WGN, bool GLDS, int ABLATE = 0, bool UNIK = false, bool CHAIN = false, bool CRES = false>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
   // (chained kernel with four 64-channel images: they take all of the staging area, the second layer's weights one buffer behind it)

@@ -52,7 +52,8 @@ def main():
         us = timeit(lambda: ops.conv2d(ops.conv2d(x, pk1, 1, out=t), pk2, 1, residual=x, out=out))
         res["two_launches_us"] = round(us, 1)
         print(f"two launches: {us:.1f} us  ({flops / us / 1e6:.0f} TFLOP/s)")
-    for v in (only or ((0, 9601, 9602, 9604, 9608) if C == 64 else (0, 9201, 9202, 9204, 9208, 9456, 9712))):
+    probes = "probes" in os.path.basename(getattr(_lib, "LIB_PATH", ""))
+    for v in (only or ((0, 9601, 9602, 9604, 9608) if C == 64 else ((0, 98, 0, 98, 9301, 9302, 9304, 9308, 9303, 9306, 9305) if probes else (0,)))):
         lib.cft_set_conv_variant(v)
         us = timeit(lambda: ops.bottleneck(x, pk1, pk2, True, out=out))
         res[f"fused_v{v}_us"] = round(us, 1)

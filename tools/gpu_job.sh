@@ -66,6 +66,9 @@ PY
     for v in 97 0 97 0; do timeout 300 python bench.py $X --conv-variant $v > $O/bench_v$v.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/bench_v$v.json'));print('variant $v', d['value'], d['ms_per_step'], d['roofline']['frac'], (d.get('single_in_flight') or {}).get('value'))" | tee -a $O/summary.txt; done ;;
   bneck)       # the fused Bottleneck kernels against the two launches + ablation probes (probe build)
     CFT_BENCH_LIB=multispectral-object-detection_amd/libcft_hip_probes.so timeout 600 python tools/bneck_bench.py 128 > $O/bneck128.log 2>&1; echo "bneck128 rc=$?"; cat $O/bneck128.log | tail -12 ;;
+  bneck6)      # round 6: the 16 x 16-tile asm Bottleneck-128 kernel (variant 0) against the round-5 kernel (97): tests, then timing
+    timeout 1200 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "bottleneck" > $O/tests.log 2>&1; echo "tests rc=$?"; tail -5 $O/tests.log
+    timeout 600 python tools/bneck_bench.py 128 > $O/bneck128.log 2>&1; echo "bneck128 rc=$?"; cat $O/bneck128.log | tail -8 ;;
   micro)       # micro-benchmarks: HBM read / write / copy ceilings; Infinity-Cache producer -> consumer; DMA stream coupling; power coupling
     for m in ${@:-hbm_rw mall_probe dma_ring power_coupling}; do timeout 200 tools/micro/$m > $O/$m.txt 2>&1; echo "$m rc=$?"; tail -40 $O/$m.txt; done ;;
   r5a)         # round 5, first call: Infinity-Cache probe; new tests (depth-first prefix, survey weights, ADVICE fixes); depth-first A/B on the forward
