@@ -176,8 +176,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4_t (&acc
 
 
 // conv_gemm_asm.hip: the 8-wave 256 x 256 kernel with the hand-scheduled K loop (16-bit operands, uniform K walk): eligibility and launch
+constexpr int CONV_ASM_NTILES = 5;                  // tile heights 256, 224, 208, 192, 128 rows (x 256 columns)
 bool conv_asm_ok(const ConvParams& p, int dtype);
-int conv_asm_launch(const ConvParams& p, int dtype, hipStream_t stream);
+int conv_asm_choose(const ConvParams& p);            // tile index whose tile count fills the CUs' rounds best, -1: too few tiles for any
+int conv_asm_tile_rows(int tile);
+int conv_asm_launch(const ConvParams& p, int dtype, int tile, hipStream_t stream);
 
 // conv_ring.hip: launch the ring kernel (dtype CFT_BF16 / CFT_F16; ablate: timing probes of -DCFT_PROBES builds, 0 otherwise)
 int conv_ring_launch(const ConvParams& p, int dtype, int ablate, hipStream_t stream);

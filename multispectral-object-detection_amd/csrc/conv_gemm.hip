@@ -526,7 +526,9 @@ static constexpr int dtype_code() { return sizeof(T) != 2 ? CFT_F32 : (__is_same
 template <typename T>
 static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   switch (g_conv_variant) {
-    case 96: if (conv_asm_ok(p, dtype_code<T>())) return conv_asm_launch(p, dtype_code<T>(), stream); break;   // the hand-scheduled 8-wave kernel wherever eligible
+    case 96: case 961: case 962: case 963: case 964:   // the hand-scheduled 8-wave kernel wherever eligible, tile heights 256 / 224 / 208 / 192 / 128 (tests)
+      if (conv_asm_ok(p, dtype_code<T>())) return conv_asm_launch(p, dtype_code<T>(), g_conv_variant == 96 ? 0 : g_conv_variant - 960, stream);
+      break;
     case 1: return launch_conv<T, 128, 128, 2, 2, false>(p, stream);   // register-staged baseline
     case 2: return launch_auto<T, 128, 128, 2, 2>(p, stream);
     case 4: return launch_auto<T, 128, 64, 2, 2>(p, stream);
@@ -595,13 +597,17 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   // wide layers: prefer 256-wide tiles unless the N tail would waste much more than 128-wide tiles do
   const long pad256 = (long)((p.N + 255) / 256) * 256, pad128 = (long)((p.N + 127) / 128) * 128;
   const bool wide_ok = pad256 * 100 <= pad128 * 115;
+  // the hand-scheduled 8-wave kernel (conv_gemm_asm.hip: bit-identical, K loop at 1.27 instead of 1.5 us per 256-row step) from 12 K steps on (below that
+  // the 16-wave kernel's shorter prologue + epilogue outweigh the loop, profiles/r06_asm_kloop.md), its tile height picked so that the tile count
+  // fills whole rounds of the CUs; variant 97: the round-5 choice
+  if (wide_ok && g_conv_variant != 97 && p.Kpad >= 12 * 64 && p.ksplit <= 1 && conv_asm_ok(p, dtype_code<T>())) {
+    const int tile = conv_asm_choose(p);
+    if (tile >= 0) return conv_asm_launch(p, dtype_code<T>(), tile, stream);
+  }
   if (wide_ok && p.Kpad >= 256 && tiles(256, 256) >= kCUs) {
 #ifdef CFT_PROBES
     if (g_conv_variant == 90 && ring_ok<T>(p)) return launch_ring<T>(p, stream);    // A/B: the 8-wave kernel in place of the 16-wave 256x256 tile
 #endif
-    // the hand-scheduled 8-wave form of this tile (conv_gemm_asm.hip: bit-identical, K loop at 1.27 instead of 1.5 us per step); variant 97: the round-5 choice
-    // (taken from 12 K steps on: below that the 16-wave kernel's shorter prologue + epilogue outweigh the loop, profiles/r06_asm_kloop.md)
-    if (g_conv_variant != 97 && p.Kpad >= 12 * 64 && conv_asm_ok(p, dtype_code<T>())) return conv_asm_launch(p, dtype_code<T>(), stream);
     return launch_auto<T, 256, 256, 4, 4>(p, stream);
   }
   if (wide_ok && tiles(128, 256) >= kCUs) return launch_auto<T, 128, 256, 4, 4>(p, stream);   // e.g. CFT fc2 at M = 8192

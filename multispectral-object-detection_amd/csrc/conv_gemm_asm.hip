@@ -51,11 +51,22 @@ __device__ __forceinline__ void asm_static_for_impl(std::integer_sequence<int, I
 template <int N, class F>
 __device__ __forceinline__ void asm_static_for(F&& f) { asm_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
+// the asm text of a (type, staging form, tile) - wave group 0 runs the MT0-row text, group 1 the MT1-row text (tools/gen_conv_asm.py TILES)
+#define CONV_ASM_RUN(TN_, MN_, M0_, M1_, AP_)                                                                              \
+  if (wm == 0) { CONV_ASM_STMT(CONV_ASM_LOOP_##TN_##_##MN_##_M##M0_##_P##AP_##_G0); }                                      \
+  else { CONV_ASM_STMT(CONV_ASM_LOOP_##TN_##_##MN_##_M##M1_##_P##AP_##_G1); }
+#define CONV_ASM_TILES(TN_, MN_)                                                                                           \
+  if constexpr (MT0 == 8 && MT1 == 8) { CONV_ASM_RUN(TN_, MN_, 8, 8, 4) }                                                  \
+  else if constexpr (MT0 == 7 && MT1 == 7) { CONV_ASM_RUN(TN_, MN_, 7, 7, 4) }                                             \
+  else if constexpr (MT0 == 7 && MT1 == 6) { CONV_ASM_RUN(TN_, MN_, 7, 6, 4) }                                             \
+  else if constexpr (MT0 == 6 && MT1 == 6) { CONV_ASM_RUN(TN_, MN_, 6, 6, 3) }                                             \
+  else { static_assert(MT0 == 4 && MT1 == 4, "tile not generated"); CONV_ASM_RUN(TN_, MN_, 4, 4, 2) }
+
 // The epilogue of conv_common.h (conv_epilogue_impl: wave-private 16-row fp32 strips in LDS, + bias, activation, + residual, one rounding,
 // coalesced 16-byte stores) for a 128 x 64 wave tile whose accumulators live in a[0:127]: strip i reads its four tiles right before use.
-template <typename TH, int ACT, bool OUT_F32>
-__device__ __forceinline__ void conv_epilogue_agpr(const ConvParams& p, unsigned char* smem, int m0, int n0, int wm, int wn, int wave, int lane, const float (&bias_v)[4]) {
-  constexpr int WM = 128, WN = 64, MT = 8, NT = 4;
+template <typename TH, int ACT, bool OUT_F32, int MT>
+__device__ __forceinline__ void conv_epilogue_agpr(const ConvParams& p, unsigned char* smem, int m0, int n0, int row0, int wn, int wave, int lane, const float (&bias_v)[4]) {
+  constexpr int WN = 64, NT = 4;
   const int lrow = lane & 15, lgrp = lane >> 4;
   constexpr int SLD = WN + 4;
   float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SLD);
@@ -67,21 +78,22 @@ __device__ __forceinline__ void conv_epilogue_agpr(const ConvParams& p, unsigned
     for (int v_ = 0; v_ < VPL; ++v_) {
       const int it_ = lane + v_ * 64;
       const int row_ = it_ / VPRB, col_ = (it_ - row_ * VPRB) * 8;
-      const int m_ = m0 + wm * WM + strip * 16 + row_, n_ = n0 + wn * WN + col_;
+      const int m_ = m0 + row0 + strip * 16 + row_, n_ = n0 + wn * WN + col_;
       gran_t t_ = {0u, 0u, 0u, 0u};
       if (m_ < p.M && n_ < p.N) t_ = *reinterpret_cast<const gran_t*>(p.res + ((long)m_ * p.ldr + p.roff + n_) * 2);
       rpre[strip % RDEPTH][v_] = t_;
     }
   };
   if constexpr (!OUT_F32) {
-    if (res_pre) { res_fetch(0); res_fetch(1); }
+    if (res_pre) { res_fetch(0); if (MT > 1) res_fetch(1); }
   }
   // strips go through LDS in PAIRS (two 16-row stages per wave): with eight waves per workgroup a wave walks eight strips, and one strip at a
   // time leaves the LDS round trip and the store latency of every strip exposed (round 4: 11.8 us against 8.5 for the 16-wave kernel)
   float* stage2[2] = {stage, stage + 8 * (16 * SLD)};
-  asm_static_for<MT / 2>([&](auto pc) {
+  asm_static_for<(MT + 1) / 2>([&](auto pc) {
     constexpr int i0 = 2 * decltype(pc)::value;
-    asm_static_for<2>([&](auto sc) {
+    constexpr int NS = (i0 + 1 < MT) ? 2 : 1;             // (an odd strip count ends with a single strip)
+    asm_static_for<NS>([&](auto sc) {
       constexpr int s_ = decltype(sc)::value;
       asm_static_for<NT>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -95,10 +107,10 @@ __device__ __forceinline__ void conv_epilogue_agpr(const ConvParams& p, unsigned
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int nbase = n0 + wn * WN;
 #pragma unroll
-    for (int s_ = 0; s_ < 2; ++s_) {
+    for (int s_ = 0; s_ < NS; ++s_) {
       const int i = i0 + s_;
       const float* st = stage2[s_];
-      const int mbase = m0 + wm * WM + i * 16;
+      const int mbase = m0 + row0 + i * 16;
       if constexpr (OUT_F32) {
         constexpr int VPR = WN / 4;
 #pragma unroll
@@ -154,7 +166,7 @@ __device__ __forceinline__ void conv_epilogue_agpr(const ConvParams& p, unsigned
       }
     }
     if constexpr (!OUT_F32) {
-      if (res_pre && i0 + 2 < MT) { res_fetch(i0 + 2); res_fetch(i0 + 3); }
+      if (res_pre && i0 + 2 < MT) { res_fetch(i0 + 2); if (i0 + 3 < MT) res_fetch(i0 + 3); }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -162,10 +174,13 @@ __device__ __forceinline__ void conv_epilogue_agpr(const ConvParams& p, unsigned
   });
 }
 
-template <typename T, bool MASKED>
+// Tile: 16 (MT0 + MT1) rows x 256 columns; wave group 0 (waves 0-3) owns the first MT0 16-row m-tiles, group 1 (waves 4-7) the next MT1 - a SIMD holds one
+// wave of each, so MT0 + MT1 MFMA rows per SIMD whatever the split.  The height is chosen per launch (conv_asm_choose) so that the tile count fills whole
+// rounds of the 256 CUs: 25 600 rows x 512 columns are 200 tiles of 256 rows (78 % of a round) or 230 of 224; 8 192 x 1 024: 128 tiles of 256 or 256 of 128.
+template <typename T, bool MASKED, int MT0, int MT1>
 __global__ void __launch_bounds__(512) conv_gemm_asm_kernel(const ConvAsmParams ap) {
   static_assert(sizeof(T) == 2, "16-bit operand types only");
-  constexpr int BM = 256, BN = 256, GE = 8, ES = 2;
+  constexpr int BM = 16 * (MT0 + MT1), BN = 256, GE = 8, ES = 2, AP = (BM + 63) / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const ConvParams& p = ap.p;
 
@@ -193,7 +208,7 @@ __global__ void __launch_bounds__(512) conv_gemm_asm_kernel(const ConvAsmParams 
     const int m = m0 + rs + i * 64;
     int a_off = 0;
     uint32_t mk = 0;
-    if (m < p.M) {
+    if (i < AP && rs + i * 64 < BM && m < p.M) {
       const int t = fast_div(m, p.wo_mul, p.wo_sh);
       const int wo = m - t * p.Wo;
       const int b = fast_div(t, p.ho_mul, p.ho_sh);
@@ -222,7 +237,7 @@ __global__ void __launch_bounds__(512) conv_gemm_asm_kernel(const ConvAsmParams 
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const uint32_t rd = (uint32_t)(lrow * 128 + (((h * 4 + lgrp) ^ (lrow & 7)) << 4));
-    ra[h] = lds0 + wm * 16384u + rd;
+    ra[h] = lds0 + (uint32_t)(wm * MT0 * 16 * 128) + rd;
     rb[h] = lds0 + 65536u + wn * 8192u + rd;
   }
   float bias_v[4];
@@ -236,13 +251,8 @@ __global__ void __launch_bounds__(512) conv_gemm_asm_kernel(const ConvAsmParams 
 #endif
   uint32_t toff = 0, cnt = (uint32_t)ap.npairs, m0s;
   const uint32_t voob = OOB;
-  if (wm == 0) {
-    if constexpr (__is_same(T, f16_t)) { if constexpr (MASKED) { CONV_ASM_STMT(CONV_ASM_LOOP_F16_MASK_G0); } else { CONV_ASM_STMT(CONV_ASM_LOOP_F16_NOMASK_G0); } }
-    else { if constexpr (MASKED) { CONV_ASM_STMT(CONV_ASM_LOOP_BF16_MASK_G0); } else { CONV_ASM_STMT(CONV_ASM_LOOP_BF16_NOMASK_G0); } }
-  } else {
-    if constexpr (__is_same(T, f16_t)) { if constexpr (MASKED) { CONV_ASM_STMT(CONV_ASM_LOOP_F16_MASK_G1); } else { CONV_ASM_STMT(CONV_ASM_LOOP_F16_NOMASK_G1); } }
-    else { if constexpr (MASKED) { CONV_ASM_STMT(CONV_ASM_LOOP_BF16_MASK_G1); } else { CONV_ASM_STMT(CONV_ASM_LOOP_BF16_NOMASK_G1); } }
-  }
+  if constexpr (__is_same(T, f16_t)) { if constexpr (MASKED) { CONV_ASM_TILES(F16, MASK) } else { CONV_ASM_TILES(F16, NOMASK) } }
+  else { if constexpr (MASKED) { CONV_ASM_TILES(BF16, MASK) } else { CONV_ASM_TILES(BF16, NOMASK) } }
   // (the asm block ends with vmcnt(0) lgkmcnt(0): this wave's requests have landed, its reads returned; the strips alias the staging buffers)
   __builtin_amdgcn_s_barrier();
   // The epilogue's launch parameters are re-read from the kernel-argument segment HERE (the pointer is laundered through an empty asm so
@@ -255,15 +265,20 @@ __global__ void __launch_bounds__(512) conv_gemm_asm_kernel(const ConvAsmParams 
   const ConvParams& pe = p;
 #endif
 
-  if (pe.out_f32) {
-    if (pe.act == CFT_ACT_SILU) conv_epilogue_agpr<T, CFT_ACT_SILU, true>(pe, smem, m0, n0, wm, wn, wave, lane, bias_v);
-    else if (pe.act == CFT_ACT_GELU) conv_epilogue_agpr<T, CFT_ACT_GELU, true>(pe, smem, m0, n0, wm, wn, wave, lane, bias_v);
-    else conv_epilogue_agpr<T, CFT_ACT_NONE, true>(pe, smem, m0, n0, wm, wn, wave, lane, bias_v);
-  } else {
-    if (pe.act == CFT_ACT_SILU) conv_epilogue_agpr<T, CFT_ACT_SILU, false>(pe, smem, m0, n0, wm, wn, wave, lane, bias_v);
-    else if (pe.act == CFT_ACT_GELU) conv_epilogue_agpr<T, CFT_ACT_GELU, false>(pe, smem, m0, n0, wm, wn, wave, lane, bias_v);
-    else conv_epilogue_agpr<T, CFT_ACT_NONE, false>(pe, smem, m0, n0, wm, wn, wave, lane, bias_v);
+#define CONV_ASM_EPI(MT_, ROW0_)                                                                                            \
+  if (pe.out_f32) {                                                                                                        \
+    if (pe.act == CFT_ACT_SILU) conv_epilogue_agpr<T, CFT_ACT_SILU, true, MT_>(pe, smem, m0, n0, ROW0_, wn, wave, lane, bias_v);       \
+    else if (pe.act == CFT_ACT_GELU) conv_epilogue_agpr<T, CFT_ACT_GELU, true, MT_>(pe, smem, m0, n0, ROW0_, wn, wave, lane, bias_v);  \
+    else conv_epilogue_agpr<T, CFT_ACT_NONE, true, MT_>(pe, smem, m0, n0, ROW0_, wn, wave, lane, bias_v);                  \
+  } else {                                                                                                                 \
+    if (pe.act == CFT_ACT_SILU) conv_epilogue_agpr<T, CFT_ACT_SILU, false, MT_>(pe, smem, m0, n0, ROW0_, wn, wave, lane, bias_v);      \
+    else if (pe.act == CFT_ACT_GELU) conv_epilogue_agpr<T, CFT_ACT_GELU, false, MT_>(pe, smem, m0, n0, ROW0_, wn, wave, lane, bias_v); \
+    else conv_epilogue_agpr<T, CFT_ACT_NONE, false, MT_>(pe, smem, m0, n0, ROW0_, wn, wave, lane, bias_v);                 \
   }
+  if constexpr (MT0 == MT1) { CONV_ASM_EPI(MT0, wm * MT0 * 16) }
+  else if (wm == 0) { CONV_ASM_EPI(MT0, 0) }
+  else { CONV_ASM_EPI(MT1, MT0 * 16) }
+#undef CONV_ASM_EPI
 }
 
 // ------------------------------------------------------------------------------------ host
@@ -277,19 +292,61 @@ bool conv_asm_ok(const ConvParams& p, int dtype) {
   return p.x_bytes + 2L * ((long)p.W + 1) * p.ldx * 2 < (1L << 31) && p.w_bytes < (1L << 31);
 }
 
-template <typename T, bool MASKED>
+template <typename T, bool MASKED, int MT0, int MT1>
 static int launch_asm_t(const ConvAsmParams& ap, int grid, hipStream_t stream) {
   constexpr int smem_bytes = 2 * (256 + 256) * 128;
-  cft_allow_lds<&conv_gemm_asm_kernel<T, MASKED>>(smem_bytes);
-  hipLaunchKernelGGL((conv_gemm_asm_kernel<T, MASKED>), dim3(grid), dim3(512), smem_bytes, stream, ap);
+  cft_allow_lds<&conv_gemm_asm_kernel<T, MASKED, MT0, MT1>>(smem_bytes);
+  hipLaunchKernelGGL((conv_gemm_asm_kernel<T, MASKED, MT0, MT1>), dim3(grid), dim3(512), smem_bytes, stream, ap);
   return cft_check_launch("conv_gemm_asm_kernel");
 }
 
-int conv_asm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
-  if (!conv_asm_ok(p, dtype)) { cft_set_error("conv_gemm_asm_kernel: layer not eligible"); return CFT_EINVAL; }
+template <typename T, bool MASKED>
+static int launch_asm_tile(const ConvAsmParams& ap, int tile, int grid, hipStream_t stream) {
+  switch (tile) {
+    case 0: return launch_asm_t<T, MASKED, 8, 8>(ap, grid, stream);
+    case 1: return launch_asm_t<T, MASKED, 7, 7>(ap, grid, stream);
+    case 2: return launch_asm_t<T, MASKED, 7, 6>(ap, grid, stream);
+    case 3: return launch_asm_t<T, MASKED, 6, 6>(ap, grid, stream);
+    default: return launch_asm_t<T, MASKED, 4, 4>(ap, grid, stream);
+  }
+}
+
+static const int kAsmTileRows[CONV_ASM_NTILES] = {256, 224, 208, 192, 128};
+int conv_asm_tile_rows(int tile) { return tile >= 0 && tile < CONV_ASM_NTILES ? kAsmTileRows[tile] : 0; }
+
+// Tile height of a launch: the one whose tile count wastes least of the 256 CUs' rounds.  Model (us), from tools/gemm_bench.py and the K-loop micro-benchmark:
+// a K step costs max(1.27 BM / 256 [matrix pipe at the clock this load holds], 0.3 + 0.3 BM / 256 [the L2 -> LDS request stream: BM + 256 rows of 128 B]),
+// a tile 5 + 6 BM / 256 on top (prologue, epilogue); rounds = ceil(tiles / 256).  Ties go to the taller tile (fewer weight re-fetches).  -1: too few tiles
+// for any height (the caller falls back to the 16-wave tiles).
+int conv_asm_choose(const ConvParams& p) {
+  const int nk = p.Kpad / 64;
+  const long tilesN = (p.N + 255) / 256;
+  int best = -1;
+  double best_t = 0.0;
+  for (int c = 0; c < CONV_ASM_NTILES; ++c) {
+    const int bm = kAsmTileRows[c];
+    const long tiles = ((long)p.M + bm - 1) / bm * tilesN;
+    if (tiles < 160) continue;
+    const long rounds = (tiles + 255) / 256;
+    const double f = bm / 256.0;
+    const double step = 1.27 * f > 0.3 + 0.3 * f ? 1.27 * f : 0.3 + 0.3 * f;
+    const double t = rounds * (nk * step + 5.0 + 6.0 * f);
+    if (best < 0 || t < best_t * 0.90) { best = c; best_t = t; }
+    // Shorter tiles only where the 256-row tiling does not even fill ONE round of the chip (measured, profiles/r06_asm_kloop.md: with two forwards in
+    // flight the idle CUs of a partial LAST round of a multi-round launch are taken by the other forward's kernels, and shorter tiles then only add
+    // weight re-fetches and prologues: -1.5 % pairs/s when every launch picks its best isolated height; a launch that leaves CUs idle for its whole
+    // duration - 200 or 128 tiles - is different)
+    if (c == 0 && tiles > 256) break;
+  }
+  return best;
+}
+
+int conv_asm_launch(const ConvParams& p, int dtype, int tile, hipStream_t stream) {
+  if (!conv_asm_ok(p, dtype) || tile < 0 || tile >= CONV_ASM_NTILES) { cft_set_error("conv_gemm_asm_kernel: layer not eligible"); return CFT_EINVAL; }
   ConvAsmParams ap;
   ap.p = p;
-  const int tilesM = (p.M + 255) / 256;
+  const int bm = kAsmTileRows[tile];
+  const int tilesM = (p.M + bm - 1) / bm;
   ap.p.tilesN = (p.N + 255) / 256;
   ap.p.ksplit = 1;
   const int nk = p.Kpad / 64, nkp = (nk + 1) & ~1;
@@ -314,6 +371,6 @@ int conv_asm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
   const bool masked = p.KS > 1 || (nk & 1);
   ap.masked = masked;
   const int grid = tilesM * ap.p.tilesN;
-  if (dtype == CFT_BF16) return masked ? launch_asm_t<uint16_t, true>(ap, grid, stream) : launch_asm_t<uint16_t, false>(ap, grid, stream);
-  return masked ? launch_asm_t<f16_t, true>(ap, grid, stream) : launch_asm_t<f16_t, false>(ap, grid, stream);
+  if (dtype == CFT_BF16) return masked ? launch_asm_tile<uint16_t, true>(ap, tile, grid, stream) : launch_asm_tile<uint16_t, false>(ap, tile, grid, stream);
+  return masked ? launch_asm_tile<f16_t, true>(ap, tile, grid, stream) : launch_asm_tile<f16_t, false>(ap, tile, grid, stream);
 }

@@ -762,11 +762,13 @@ ASM_CASES = [
 
 
 @pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
+@pytest.mark.parametrize("avariant", [96, 961, 962, 963, 964], ids=["h256", "h224", "h208", "h192", "h128"])
 @pytest.mark.parametrize("case", ASM_CASES, ids=[f"a{i}" for i in range(len(ASM_CASES))])
-def test_asm_gemm_kernel_is_bit_identical(dev, dtype, case):
-    """The 8-wave kernel with the hand-scheduled (inline-asm) K loop (csrc/conv_gemm_asm.hip, variant 96 = wherever eligible; the automatic
-    choice takes it for the wide layers) against the generic address path of the 16-wave kernel (variant 900): same fetches, same LDS image,
-    same k order per accumulator -> the same bits, with and without a shortcut, and close to torch's fp32 convolution."""
+def test_asm_gemm_kernel_is_bit_identical(dev, dtype, case, avariant):
+    """The 8-wave kernel with the hand-scheduled (inline-asm) K loop (csrc/conv_gemm_asm.hip; variants 96 / 961-964 = wherever eligible with tiles
+    of 256 / 224 / 208 / 192 / 128 rows - the automatic choice takes it for the wide layers with the height that fills the CUs' rounds) against
+    the generic address path of the 16-wave kernel (variant 900): same fetches, same LDS image, same k order per accumulator -> the same bits,
+    with and without a shortcut, and close to torch's fp32 convolution."""
     from msod_amd import _lib, ops
     B, H, W, Cin, Cout, k, s_, use_res = case
     x = _q(_rnd(B, Cin, H, W, seed=91), dtype)
@@ -776,7 +778,7 @@ def test_asm_gemm_kernel_is_bit_identical(dev, dtype, case):
     xd = to_dev_nhwc(x, dev, dtype)
     lib = _lib.load()
     outs = {}
-    for v in (900, 96):
+    for v in (900, avariant):
         lib.cft_set_conv_variant(v)
         try:
             y0 = ops.conv2d(xd, pk, 1)
@@ -785,10 +787,10 @@ def test_asm_gemm_kernel_is_bit_identical(dev, dtype, case):
             torch.cuda.synchronize()
         finally:
             lib.cft_set_conv_variant(0)
-    for a, c in zip(outs[900], outs[96]):
+    for a, c in zip(outs[900], outs[avariant]):
         assert torch.equal(a.float().cpu(), c.float().cpu())
     ref = F.silu(F.conv2d(x, w, b, s_, k // 2))
-    assert rel_err(to_cpu_f32(outs[96][0])[:, :Cout], ref) < tol(dtype)
+    assert rel_err(to_cpu_f32(outs[avariant][0])[:, :Cout], ref) < tol(dtype)
 
 
 @pytest.mark.parametrize("dtype", LOWP, ids=["bf16", "f16"])
@@ -803,7 +805,7 @@ def test_asm_gemm_kernel_linear_forms(dev, dtype, rows, K, N):
     resid = _rnd(rows, N, seed=8).to(dev)
     lib = _lib.load()
     outs = {}
-    for v in (900, 96):
+    for v in (900, 96, 0, 964):
         lib.cft_set_conv_variant(v)
         try:
             o = [ops.linear(x, pk, ops.ACT_GELU), ops.linear(x, pk, ops.ACT_NONE, residual=resid, out_dtype=torch.float32), ops.linear(x, pk)]
@@ -813,8 +815,9 @@ def test_asm_gemm_kernel_linear_forms(dev, dtype, rows, K, N):
             outs[v] = o
         finally:
             lib.cft_set_conv_variant(0)
-    for a, c in zip(outs[900], outs[96][:3]):
-        assert torch.equal(a.float().cpu(), c.float().cpu())
+    for v in (96, 0, 964):                      # (0: the automatic choice - the tile height that fills the CUs' rounds)
+        for a, c in zip(outs[900], outs[v][:3]):
+            assert torch.equal(a.float().cpu(), c.float().cpu())
     for c in outs[96][3:]:
         assert torch.equal(c, outs[96][2])
 

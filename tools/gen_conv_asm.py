@@ -32,6 +32,7 @@ The two wave groups (waves 0-3 / 4-7: a SIMD holds one wave of each) place their
 import os
 import sys
 
+TILES = [(8, 8), (7, 7), (7, 6), (6, 6), (4, 4)]      # (m-tiles of wave group 0, of group 1): tile heights 256, 224, 208, 192, 128
 FA = [32, 80]
 FB = [64, 112]
 VO = 28          # v[28:31]: masked A voffsets
@@ -45,26 +46,26 @@ def mfma(op, i, j, h):
     return f"{op} a[{a}:{a+3}], v[{FA[h]+4*i}:{FA[h]+4*i+3}], v[{FB[h]+4*j}:{FB[h]+4*j+3}], a[{a}:{a+3}]"
 
 
-def reads(h, c):
+def reads(h, c, mt=8):
     out = []
     for j in range(4):
         out.append(f"ds_read_b128 v[{FB[h]+4*j}:{FB[h]+4*j+3}], %[rb{h}] offset:{c*32768 + j*2048}")
-    for i in range(8):
+    for i in range(mt):
         out.append(f"ds_read_b128 v[{FA[h]+4*i}:{FA[h]+4*i+3}], %[ra{h}] offset:{c*32768 + i*2048}")
     return out
 
 
-def mask_ops(q, masked):
+def mask_ops(q, masked, ap=4):
     """v[28+i] = (amask_i & tapbit) ? voa_i : OOB, tapbit = s[q+2]; one list per A row pass"""
     if not masked:
         return []
-    return [[f"v_and_b32 v{VT}, s{q+2}, %[am{i}]", f"v_cmp_ne_u32 vcc, 0, v{VT}", f"v_cndmask_b32 v{VO+i}, {OOB}, %[voa{i}], vcc"] for i in range(4)]
+    return [[f"v_and_b32 v{VT}, s{q+2}, %[am{i}]", f"v_cmp_ne_u32 vcc, 0, v{VT}", f"v_cndmask_b32 v{VO+i}, {OOB}, %[voa{i}], vcc"] for i in range(ap)]
 
 
-def dmas(c, q, masked):
-    """the 8 LDS-DMA requests of one K step into buffer c, offsets from table quad s[q:q+3]"""
+def dmas(c, q, masked, ap=4):
+    """the ap + 4 LDS-DMA requests of one K step into buffer c (ap 64-row passes of the A image, 4 of the B image), offsets from table quad s[q:q+3]"""
     out = []
-    for i in range(4):
+    for i in range(ap):
         vo = f"v{VO+i}" if masked else f"%[voa{i}]"
         out.append([f"s_add_u32 m0, %[wb], {c*32768 + i*8192}", "s_nop 0", f"buffer_load_dwordx4 {vo}, %[srda], s{q} offen lds"])
     for i in range(4):
@@ -91,44 +92,47 @@ def interleave(mf, fillers):
     return out
 
 
-def step(op, c, g, masked):
-    order = [(i, j) for i in range(8) for j in range(4)]
+def step(op, c, g, masked, mt=8, ap=4):
+    order = [(i, j) for i in range(mt) for j in range(4)]
     mf0 = [mfma(op, i, j, 0) for (i, j) in order]
     mf1 = [mfma(op, i, j, 1) for (i, j) in order]
+    n, nr, nd = 4 * mt, mt + 4, ap + 4
     q = QUAD[c]
     f0 = [(-1, table_load(QUAD[c ^ 1]))]
-    f0 += [(k, [r]) for k, r in enumerate(reads(1, c))]                       # slots 0..11
-    f0 += [(14 + 4 * k, m) for k, m in enumerate(mask_ops(q, masked))]        # slots 14, 18, 22, 26
+    f0 += [(k, [r]) for k, r in enumerate(reads(1, c, mt))]                   # slots 0 .. mt+3
+    ms = max(1, (n - nr - 2) // max(ap, 1))
+    f0 += [(nr + 2 + ms * k, m) for k, m in enumerate(mask_ops(q, masked, ap))]   # behind the reads, spread over the rest of the half
     out = interleave(mf0, f0)
     out += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
-    d0 = 0 if g == 0 else 2
-    f1 = [(d0 + 4 * k, d) for k, d in enumerate(dmas(c, q, masked))]          # slots d0, d0+4, .. d0+28
-    f1 += [(1 + 2 * k, [r]) for k, r in enumerate(reads(0, c ^ 1))]           # slots 1, 3, .. 23
+    ds = 4 if n >= 4 * nd else (3 if n >= 3 * nd else 2)                      # one request per ds MFMA slots; the two wave groups ds/2 slots apart
+    d0 = 0 if g == 0 else ds // 2
+    f1 = [(d0 + ds * k, d) for k, d in enumerate(dmas(c, q, masked, ap))]
+    f1 += [(1 + 2 * k, [r]) for k, r in enumerate(reads(0, c ^ 1, mt))]       # odd slots
     out += interleave(mf1, f1)
     out += ["s_waitcnt lgkmcnt(0)"]
     return out
 
 
-def loop_text(op, g, masked):
+def loop_text(op, g, masked, mt=8, ap=4):
     L = ["s_mov_b32 %[m0s], m0"]
     # prologue: table entries 0 / 1 -> requests of steps 0 / 1; entry 2 -> quad 0; (accumulators zeroed under the requests' flight;) wait
     # for step 0; read its k half 0
     L += table_load(QUAD[0]) + table_load(QUAD[1]) + ["s_waitcnt lgkmcnt(0)"]
     for c in (0, 1):
-        for m in mask_ops(QUAD[c], masked):
+        for m in mask_ops(QUAD[c], masked, ap):
             L += m
-        for d in dmas(c, QUAD[c], masked):
+        for d in dmas(c, QUAD[c], masked, ap):
             L += d
     L += table_load(QUAD[0])
-    for a in range(128):
+    for a in range(16 * mt):
         L.append(f"v_accvgpr_write_b32 a{a}, 0")
-    L += ["s_waitcnt vmcnt(8)", "s_barrier"]
-    L += reads(0, 0)
+    L += [f"s_waitcnt vmcnt({ap + 4})", "s_barrier"]
+    L += reads(0, 0, mt)
     L += ["s_waitcnt lgkmcnt(0)"]
     # the loop computes its masked offsets in half 0 of each step from quad[c]: entry 2 is in quad 0 now
     L += [".p2align 6", "1:"]
-    L += step(op, 0, g, masked)
-    L += step(op, 1, g, masked)
+    L += step(op, 0, g, masked, mt, ap)
+    L += step(op, 1, g, masked, mt, ap)
     L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 1b"]
     L += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_nop 15", "s_nop 15", "s_mov_b32 m0, %[m0s]"]
     return L
@@ -143,12 +147,21 @@ def emit(f):
                 f'asm volatile("v_accvgpr_read_b32 %0, a{4*t}\\n\\tv_accvgpr_read_b32 %1, a{4*t+1}\\n\\tv_accvgpr_read_b32 %2, a{4*t+2}\\n\\tv_accvgpr_read_b32 %3, a{4*t+3}" '
                 f': "=v"(a), "=v"(b), "=v"(c), "=v"(d)); return f32x4_t{{a, b, c, d}}; }}\n')
     f.write("\n")
+    # one text per (operand type, masked / unmasked staging, m-tiles of the wave group, A passes of the tile): the tile is 16 (MT0 + MT1) rows,
+    # wave group 0 (waves 0-3) owns the first MT0 m-tiles, group 1 the next MT1 (a SIMD holds one wave of each: MT0 + MT1 MFMA rows per SIMD)
+    done = set()
     for tname, op in (("BF16", "v_mfma_f32_16x16x32_bf16"), ("F16", "v_mfma_f32_16x16x32_f16")):
         for mname, masked in (("MASK", True), ("NOMASK", False)):
-            for g in (0, 1):
-                f.write(f"#define CONV_ASM_LOOP_{tname}_{mname}_G{g} \\\n")
-                f.write(" \\\n".join(f'  "{l}\\n\\t"' for l in loop_text(op, g, masked)))
-                f.write("\n\n")
+            for (mt0, mt1) in TILES:
+                ap = (16 * (mt0 + mt1) + 63) // 64
+                for g, mt in ((0, mt0), (1, mt1)):
+                    name = f"CONV_ASM_LOOP_{tname}_{mname}_M{mt}_P{ap}_G{g}"
+                    if name in done:
+                        continue
+                    done.add(name)
+                    f.write(f"#define {name} \\\n")
+                    f.write(" \\\n".join(f'  "{l}\\n\\t"' for l in loop_text(op, g, masked, mt, ap)))
+                    f.write("\n\n")
 
 
 if __name__ == "__main__":
