@@ -100,7 +100,7 @@ def traffic_from_profile(args, n_launch, abytes):
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh ->
     profiles/*_traffic.json: FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, summed
     over the conv_gemm family of one forward).  Only reported for the configuration it was collected on."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (6, 5, 4, 3, 2, 1)) if os.path.exists(q)), None)
     if path is None:
         return None
     t = json.load(open(path))
@@ -354,6 +354,8 @@ def main():
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--no-concat-plan", action="store_true", help="A/B: let Concat copy all its sources")
     ap.add_argument("--no-conv-chain", action="store_true", help="A/B: the stride-2 Conv in front of a C3 and the C3's cv1|cv2 as two launches (round 3) instead of one")
+    ap.add_argument("--no-pair-chain", action="store_true", help="A/B: the 256-channel Bottleneck pairs (3x3 [+ shortcut] + next 1x1) as two launches each "
+                    "(the 3x3 then runs on the hand-scheduled kernel) instead of the chained 16-wave kernel")
     ap.add_argument("--no-cft-fusion", action="store_true", help="A/B: de-tokenise + Add2 per stream and Add as three launches (round 3) instead of one")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-f16-leg", action="store_true", help="skip the extra fp16 measurement (N = 1, 16-bit runs only)")
@@ -400,6 +402,9 @@ def main():
     model.plan_concats = not args.no_concat_plan
     model.fuse_cft_outputs = not args.no_cft_fusion
     model.chain_convs = not args.no_conv_chain
+    if args.no_pair_chain:
+        from msod_amd.models.common import C3
+        C3.chain_pairs = False
     model.splitk = not args.no_splitk
     model.fuse_stem = args.stem
     if args.depth_first:

@@ -16,6 +16,9 @@
 #include <utility>
 #include "conv_gemm_asm.inc"
 
+#ifndef CONV_ASM_STRIPS
+#define CONV_ASM_STRIPS 2       // strips in flight per wave in the epilogue
+#endif
 constexpr int ASM_MAXE = 236;                 // table entries: K steps (rounded up to even) + 3
 struct ConvAsmParams {
   ConvParams p;
@@ -70,7 +73,8 @@ __device__ __forceinline__ void conv_epilogue_agpr(const ConvParams& p, unsigned
   const int lrow = lane & 15, lgrp = lane >> 4;
   constexpr int SLD = WN + 4;
   float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SLD);
-  constexpr int VPRB = WN / 8, VPL = (16 * VPRB + 63) / 64, RDEPTH = 2;
+  constexpr int SG = CONV_ASM_STRIPS;                      // strips per group (each with its own 16-row stage per wave: SG x 34 KiB of the dead staging buffers)
+  constexpr int VPRB = WN / 8, VPL = (16 * VPRB + 63) / 64, RDEPTH = SG;
   gran_t rpre[OUT_F32 ? 1 : RDEPTH][OUT_F32 ? 1 : VPL];
   const bool res_pre = !OUT_F32 && p.res != nullptr && !p.res_f32;   // uniform
   auto res_fetch = [&](int strip) {
@@ -85,14 +89,20 @@ __device__ __forceinline__ void conv_epilogue_agpr(const ConvParams& p, unsigned
     }
   };
   if constexpr (!OUT_F32) {
-    if (res_pre) { res_fetch(0); if (MT > 1) res_fetch(1); }
+    if (res_pre) {
+#pragma unroll
+      for (int s_ = 0; s_ < SG; ++s_)
+        if (s_ < MT) res_fetch(s_);
+    }
   }
   // strips go through LDS in PAIRS (two 16-row stages per wave): with eight waves per workgroup a wave walks eight strips, and one strip at a
   // time leaves the LDS round trip and the store latency of every strip exposed (round 4: 11.8 us against 8.5 for the 16-wave kernel)
-  float* stage2[2] = {stage, stage + 8 * (16 * SLD)};
-  asm_static_for<(MT + 1) / 2>([&](auto pc) {
-    constexpr int i0 = 2 * decltype(pc)::value;
-    constexpr int NS = (i0 + 1 < MT) ? 2 : 1;             // (an odd strip count ends with a single strip)
+  float* stage2[SG];
+#pragma unroll
+  for (int s_ = 0; s_ < SG; ++s_) stage2[s_] = stage + s_ * 8 * (16 * SLD);
+  asm_static_for<(MT + SG - 1) / SG>([&](auto pc) {
+    constexpr int i0 = SG * decltype(pc)::value;
+    constexpr int NS = (i0 + SG <= MT) ? SG : MT - i0;     // (the last group may be short)
     asm_static_for<NS>([&](auto sc) {
       constexpr int s_ = decltype(sc)::value;
       asm_static_for<NT>([&](auto jc) {
@@ -150,7 +160,7 @@ __device__ __forceinline__ void conv_epilogue_agpr(const ConvParams& p, unsigned
             float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
             if (res_pre) {
               float rf[8];
-              Elem<TH>::unpack(rpre[s_][vi], rf);
+              Elem<TH>::unpack(rpre[(i0 + s_) % RDEPTH][vi], rf);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] += rf[e];
             } else if (p.res != nullptr) {   // fp32 residual stream of the CFT block
@@ -166,7 +176,11 @@ __device__ __forceinline__ void conv_epilogue_agpr(const ConvParams& p, unsigned
       }
     }
     if constexpr (!OUT_F32) {
-      if (res_pre && i0 + 2 < MT) { res_fetch(i0 + 2); if (i0 + 3 < MT) res_fetch(i0 + 3); }
+      if (res_pre) {
+#pragma unroll
+        for (int s_ = 0; s_ < SG; ++s_)
+          if (i0 + SG + s_ < MT) res_fetch(i0 + SG + s_);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -292,7 +292,7 @@ class C3(_Packed):
         head = cat[:, :c_]
         y = head
         n = len(self.m)
-        if self.chain and n >= 2 and not self.training and self._res_chainable(head):
+        if self.chain and self.chain_pairs and n >= 2 and not self.training and self._res_chainable(head):
             # WITH shortcuts (backbone C3s, 256 channels): Bottleneck j's output is the next shortcut AND the input of Bottleneck j + 1's 1x1 -
             # cv2[j] (+ shortcut) and cv1[j + 1] run as one launch (ops.conv2d_chain_res): n + 1 launches instead of 2 n, no re-read of y
             h = self.m[0].cv1(y)
@@ -303,7 +303,7 @@ class C3(_Packed):
             return self.cv3(cat, out=out)
         # Without shortcuts a Bottleneck's output has ONE reader, the next Bottleneck's 1x1 (reference models/common.py:108-109, :142):
         # cv2[j] + cv1[j + 1] then run as one launch (ops.conv2d_chain) and the tensor between the two Bottlenecks never exists.
-        can = [self.chain and j + 1 < n and self._chainable(self.m[j], self.m[j + 1], head) for j in range(n)]
+        can = [self.chain and self.chain_pairs and j + 1 < n and self._chainable(self.m[j], self.m[j + 1], head) for j in range(n)]
         hidden = None              # cv1 output of Bottleneck j, already produced by the chained launch of Bottleneck j - 1
         for j, blk in enumerate(self.m):
             dst = head if j == n - 1 else None
@@ -319,6 +319,7 @@ class C3(_Packed):
         return self.cv3(cat, out=out)
 
     chain = True                   # Model.chain_convs switches it (A/B)
+    chain_pairs = True             # the Bottleneck-pair chains (3x3 of Bottleneck j + 1x1 of Bottleneck j + 1) on their own (A/B: bench.py --no-pair-chain)
 
     def _res_chainable(self, y):
         """Every Bottleneck has a shortcut and (cv2[j], cv1[j + 1]) is a pair ``ops.conv2d_chain_res`` takes on tensors shaped like ``y``."""

@@ -69,6 +69,21 @@ PY
   bneck6)      # round 6: the 16 x 16-tile asm Bottleneck-128 kernel (variant 0) against the round-5 kernel (97): tests, then timing
     timeout 1200 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "bottleneck" > $O/tests.log 2>&1; echo "tests rc=$?"; tail -5 $O/tests.log
     timeout 600 python tools/bneck_bench.py 128 > $O/bneck128.log 2>&1; echo "bneck128 rc=$?"; cat $O/bneck128.log | tail -8 ;;
+  r6b)         # round 6: whole-forward A/B (variant 97 = round-5 choice, 0 = asm kernels) with the board power sampled during the sustained leg
+    rocm-smi --showmaxpower --showpower 2>&1 | grep -i -E "power|watt" | head -4 | tee $O/summary.txt
+    X="--no-cpu-baseline --no-f16-leg --no-parity --sustained-steps 400"
+    for v in 97 0 97 0; do
+      (timeout 300 python bench.py $X --conv-variant $v > $O/b_$v.json 2>> $O/bench.log &)
+      sleep 50; for i in 1 2 3 4 5 6; do cat /sys/class/drm/card*/device/hwmon/hwmon*/power1_input 2>/dev/null | tr '\n' ' '; echo; sleep 1; done | tee -a $O/power_$v.txt   # microwatts, every card of the node (ours is the one that moves)
+      wait; sleep 25
+      python -c "import json;d=json.load(open('$O/b_$v.json'));s=d.get('sustained') or {};print('variant $v', d['value'], d['ms_per_step'], (d.get('single_in_flight') or {}).get('value'), s.get('value'), (s.get('shader_clock_under_load') or {}).get('s_memtime_mhz'))" | tee -a $O/summary.txt
+    done ;;
+  pmc6)        # round 6: PMC counters of the asm-K-loop kernel (variant 96) and of the 16-wave kernel (97) on 3x3 512->512 @20 (72 K steps, 200 tiles)
+    for v in 96 97; do
+      bash tools/pmc.sh $O/v$v -- python tools/gemm_bench.py --variants $v --iters 10 --rounds 1 --only "bneck 3x3 512->512" --out $JOB/g$v.json > $O/pmc_v$v.log 2>&1
+      python tools/pmc_summary.py $O/v$v conv_gemm > $O/pmc_3x3_512ch_20x20_variant$v.txt; rm -rf $O/v$v
+      head -40 $O/pmc_3x3_512ch_20x20_variant$v.txt
+    done ;;
   micro)       # micro-benchmarks: HBM read / write / copy ceilings; Infinity-Cache producer -> consumer; DMA stream coupling; power coupling
     for m in ${@:-hbm_rw mall_probe dma_ring power_coupling}; do timeout 200 tools/micro/$m > $O/$m.txt 2>&1; echo "$m rc=$?"; tail -40 $O/$m.txt; done ;;
   r5a)         # round 5, first call: Infinity-Cache probe; new tests (depth-first prefix, survey weights, ADVICE fixes); depth-first A/B on the forward
@@ -139,7 +154,7 @@ PY
   evidence)    # PMC traffic passes, bench line, rocprofv3 kernel stats (single- and two-stream)
     bash tools/pmc_traffic.sh $O/traffic > $O/traffic.log 2>&1
     python tools/traffic_summary.py $O/traffic $O/traffic.json config=cfg3 batch=64 size=640 dtype=bf16 | tee $O/summary.txt
-    rm -rf $O/traffic; cp $O/traffic.json profiles/r05_traffic.json
+    rm -rf $O/traffic; cp $O/traffic.json profiles/r06_traffic.json
     timeout 900 python bench.py > $O/bench_bs64.json 2> $O/bench.log; echo "bench rc=$?" | tee -a $O/summary.txt
     cp gpurun_out/bench_families.json $O/gemm_families_cfg3.json
     timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof1 --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f16-leg --no-overlap --in-flight 1 --sustained-steps 0 --no-parity > $O/prof1.log 2>&1; echo "prof single-stream rc=$?" | tee -a $O/summary.txt
