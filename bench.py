@@ -364,7 +364,10 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run both backbones on one HIP stream")
     ap.add_argument("--sustained-steps", type=int, default=500, help="extra >= 10 s leg at N = 1 (0 = skip)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed configuration")
-    ap.add_argument("--in-flight", type=int, default=2, help="forwards in flight (own graphs, buffers and streams each); 1 = one at a time")
+    ap.add_argument("--in-flight", type=int, default=3, help="forwards in flight (own graphs, buffers and streams each); 1 = one at a time")
+    ap.add_argument("--fly-two-streams", action="store_true", help="A/B: the forwards in flight keep their two backbone streams (rounds 3-5 ran 2 such forwards); "
+                    "by default, from 3 in flight on, each forward in flight is captured on ONE stream (no stream-group lottery: profiles/r06_forwards_in_flight.txt) "
+                    "and the two-stream graph serves the one-at-a-time leg")
     ap.add_argument("--force-gather", action="store_true", help="N = 1: run the detection all-gather anyway (RCCL with world size 1, OverlappedGather "
                     "inside the timed steps) and report multi_gpu_selfcheck - exercises the N > 1 step mode on the one GPU of a box")
     ap.add_argument("--stem", action="store_true", help="A/B: the one-kernel stem (Focus + Conv + C3.cv1|cv2, Model.fuse_stem) instead of Focus, then the chained Conv + C3.cv1|cv2")
@@ -415,14 +418,26 @@ def main():
 
     log("weights loaded, packing + capturing")
     k_fly = 1 if args.no_graph else max(1, args.in_flight)
+    fly_single = False
     with torch.no_grad():
         if args.no_graph:
             step_seq = lambda: model.forward_once(rgb, ir)   # noqa: E731
             caps = []
         else:
             from msod_amd.graph import CapturedForward
-            caps = [model.capture(args.batch, args.size, args.size)] + [CapturedForward(model, args.batch, args.size, args.size)
-                                                                        for _ in range(k_fly - 1)]
+            # From 3 forwards in flight on, each forward in flight runs its two backbones on ONE stream: K single-stream graphs fill the chip as
+            # well as 2 two-stream ones (+2 % measured) and the throughput no longer depends on WHICH HIP streams replay them (the two attractors of
+            # rounds 3-5, 7 % apart, collapse to one).  caps[0] stays the two-stream graph: best latency for one forward at a time.
+            fly_single = k_fly >= 3 and not args.fly_two_streams and not args.no_overlap
+            caps = [model.capture(args.batch, args.size, args.size)]
+            if fly_single:
+                model.overlap_streams = False
+                fly_caps = [CapturedForward(model, args.batch, args.size, args.size) for _ in range(k_fly)]
+                model.overlap_streams = True
+                caps += fly_caps
+            else:
+                caps += [CapturedForward(model, args.batch, args.size, args.size) for _ in range(k_fly - 1)]
+                fly_caps = caps
             for c in caps:
                 c.rgb.copy_(rgb)
                 c.ir.copy_(ir)
@@ -437,7 +452,7 @@ def main():
         # backbone convolutions.  --in-flight 1 = one forward at a time (also reported as "single_in_flight").
         stream_probe_ms = None
         if k_fly > 1:
-            runners = [(lambda c=c: c.replay_static()[0]) for c in caps]
+            runners = [(lambda c=c: c.replay_static()[0]) for c in fly_caps]
             prios = [int(v) for v in args.stream_priorities.split(",")] if args.stream_priorities else None
             fly_streams, stream_probe_ms = D.ForwardPipeline.pick_streams(runners, dev, priorities=prios)      # untimed set-up: the stream group that overlaps best
             pipe = D.ForwardPipeline(runners, fly_streams, gather)
@@ -557,7 +572,8 @@ def main():
             "config": {"workload": f"{args.config} ({WORKLOADS.get(args.config, args.config)}) two-stream forward, "
                                    f"{args.size}x{args.size}, {args.batch} pairs/GPU, BN folded, pre-NMS detections",
                        "pairs_per_gpu": args.batch, "image_size": args.size, "parallelism": f"batch-shard x{world}",
-                       "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap, "forwards_in_flight": k_fly, "env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
+                       "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap and not fly_single, "forwards_in_flight": k_fly,
+                       **({"streams_per_forward_in_flight": 1, "single_in_flight_streams": 2} if fly_single else {}), "env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
                        **({"stream_group_probe_ms_per_step": stream_probe_ms} if stream_probe_ms else {}),
                        **({"depth_first": args.depth_first} if args.depth_first else {}), **({"fuse_stem": True} if args.stem else {}), **({"stream_priorities": args.stream_priorities} if args.stream_priorities else {}),
                        **({"conv_variant": args.conv_variant} if args.conv_variant else {})},
@@ -604,7 +620,9 @@ def main():
             model.set_compute_dtype(torch.float16)
             with torch.no_grad():
                 from msod_amd.graph import CapturedForward
+                model.overlap_streams = not fly_single and not args.no_overlap
                 caps16 = [CapturedForward(model, args.batch, args.size, args.size) for _ in range(k_fly)]
+                model.overlap_streams = not args.no_overlap
                 for c in caps16:
                     c.rgb.copy_(rgb)
                     c.ir.copy_(ir)
