@@ -370,7 +370,6 @@ def main():
                     "and the two-stream graph serves the one-at-a-time leg")
     ap.add_argument("--force-gather", action="store_true", help="N = 1: run the detection all-gather anyway (RCCL with world size 1, OverlappedGather "
                     "inside the timed steps) and report multi_gpu_selfcheck - exercises the N > 1 step mode on the one GPU of a box")
-    ap.add_argument("--stem", action="store_true", help="A/B: the one-kernel stem (Focus + Conv + C3.cv1|cv2, Model.fuse_stem) instead of Focus, then the chained Conv + C3.cv1|cv2")
     ap.add_argument("--no-splitk", action="store_true", help="A/B: the CFT blocks' out_proj / fc2 as one launch each (round 4) instead of split-K + LayerNorm-reduce")
     ap.add_argument("--depth-first", default="", help="CHUNKS[,ROWS]: Model.depth_first - the image-only prefix of each backbone sub-batch by sub-batch "
                     "(Infinity-Cache residency); empty = layer by layer over the whole batch")
@@ -409,7 +408,6 @@ def main():
         from msod_amd.models.common import C3
         C3.chain_pairs = False
     model.splitk = not args.no_splitk
-    model.fuse_stem = args.stem
     if args.depth_first:
         df = [int(v) for v in args.depth_first.split(",")]
         model.depth_first = (df[0], df[1] if len(df) > 1 else None)
@@ -575,7 +573,7 @@ def main():
                        "hip_graph": not args.no_graph, "two_hip_streams": not args.no_overlap and not fly_single, "forwards_in_flight": k_fly,
                        **({"streams_per_forward_in_flight": 1, "single_in_flight_streams": 2} if fly_single else {}), "env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
                        **({"stream_group_probe_ms_per_step": stream_probe_ms} if stream_probe_ms else {}),
-                       **({"depth_first": args.depth_first} if args.depth_first else {}), **({"fuse_stem": True} if args.stem else {}), **({"stream_priorities": args.stream_priorities} if args.stream_priorities else {}),
+                       **({"depth_first": args.depth_first} if args.depth_first else {}), **({"stream_priorities": args.stream_priorities} if args.stream_priorities else {}),
                        **({"conv_variant": args.conv_variant} if args.conv_variant else {})},
             "sustained": sustained, "single_in_flight": single, "multi_gpu_selfcheck": selfcheck,
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear family; incl. the dedicated Focus kernel and the fused 64- / 128-channel Bottleneck kernels: 2 + 27 launches of the cfg3 forward)",

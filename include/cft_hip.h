@@ -107,19 +107,6 @@ int cft_linear_splitk(const void* x, const void* w, const float* bias, float* pa
                       int rows, int cin, int ldx, int n, int kpad, int splits, int dtype, void* stream);
 
 /*
- * The stem of a backbone as one kernel (yolov5l widths; yaml rows 0-2 / 5-7): image -> Focus (models/common.py:168-179: 2x2 space-to-depth +
- * Conv 12 -> 64, 3x3) -> Conv 64 -> 128, 3x3, stride 2 (:45-50) -> the pointwise layer [n2][128] behind it (a C3's cv1 | cv2, :141-143).
- * The [B, H/2, W/2, 64] Focus output (839 MB per stream at 64 pairs of 640 x 640) and the stride-2 conv's output stay in LDS.
- * Arguments: the image as cft_focus_conv; wf [64][192] / bf, w1 [128][576] / b1, w2 [n2][128] / b2 (cft_conv2d layouts, BN folded);
- * y: dtype [B, H/4, W/4] pixels, ldy / yoff.  Bit-identical to cft_focus_conv followed by cft_conv2d_chain.  Eligibility: cft_stem_ok.
- */
-int cft_stem(const void* in, int in_kind, long stride_b, long stride_c, long stride_h, float scale,
-             const void* wf, int kpad_f, const float* bf, const void* w1, int kpad1, const float* b1,
-             const void* w2, const float* b2, void* y, int ldy, int yoff,
-             int B, int H, int W, int n_focus, int n1, int n2, int act2, int dtype, void* stream);
-int cft_stem_ok(int H, int W, int n_focus, int kpad_focus, int n1, int kpad1, int n2, int dtype);
-
-/*
  * Bottleneck as one kernel (models/common.py:99-109 with e = 1.0, the form C3 uses :138):
  *   y = (shortcut ? x : 0) + SiLU(conv3x3(SiLU(conv1x1(x) + b1)) + b2),  c -> c -> c channels, 16-bit dtype.
  * x, y: NHWC channel slices (ldx/xoff, ldy/yoff) that must not overlap (the kernel reads a halo of x);

@@ -15,12 +15,12 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcft_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("runtime.hip", "conv_gemm.hip", "conv_gemm_asm.hip", "focus_conv.hip", "stem.hip", "bottleneck.hip", "pointwise.hip", "attention.hip", "nms.hip", "train.hip")
+SOURCES = ("runtime.hip", "conv_gemm.hip", "conv_gemm_asm.hip", "focus_conv.hip", "bottleneck.hip", "pointwise.hip", "attention.hip", "nms.hip", "train.hip")
 
 HEADERS = ("cft_common.h", "conv_common.h", "focus_common.h", "bneck_common.h", "conv_gemm_asm.inc")
 
 CFT_BF16, CFT_F32, CFT_F16 = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 
 _c = ctypes
@@ -36,8 +36,6 @@ SIGNATURES = {
     "cft_conv2d_chain_res": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_linear_splitk": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_layernorm_reduce": [_vp, _vp, _i, _vp, _vp, _vp, _l, _i, _f, _i, _vp],
-    "cft_stem": [_vp, _i, _l, _l, _l, _f, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "cft_stem_ok": [_i, _i, _i, _i, _i, _i, _i, _i],
     "cft_conv2d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cft_set_conv_variant": [_i],
     "cft_bottleneck": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -1,3 +1,7 @@
+// PROBE BUILD ONLY since round 6 (tools/build_probes.sh): the one-kernel stem is bit-identical and removes 3.35 GB of HBM traffic per forward, but is
+// slower than the two kernels it replaces (profiles/r05_stem.md: 943 us against 313 + 463) - VERDICT r5 item 8: it left the product library, the
+// executor switch (Model.fuse_stem) and the C ABI (cft_stem / cft_stem_ok, ABI v10) with it.
+#ifdef CFT_PROBES
 // The stem of a backbone as ONE kernel for gfx950 (yolov5l widths):  image -> Focus -> Conv(64 -> 128, 3x3, stride 2) -> C3.cv1 | C3.cv2
 // (reference models/common.py:168-179 Focus, :45-50 Conv, :141-143 the two 1x1 convs of the C3 behind it, packed as one [N2][128] weight;
 // yaml rows 0-2 / 5-7 of the fusion configs).
@@ -26,8 +30,8 @@
 // per CU do not hide (the skeleton alone - barriers, patch build, image writes, pointwise GEMM - costs 6.4 us per tile).  An 8 x 16-tile,
 // one-workgroup-per-CU form measured 1020 - 1030 us and was removed.  The kernel is therefore OPT-IN (Model.fuse_stem, default off): it
 // trades 7 % of the forward's HBM traffic for no time.
-#include "cft_common.h"
-#include "focus_common.h"
+#include "../cft_common.h"
+#include "../focus_common.h"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -407,3 +411,5 @@ extern "C" int cft_stem(const void* in, int in_kind, long stride_b, long stride_
   hipStream_t s = as_stream(stream);
   return dtype == CFT_BF16 ? dispatch_stem<uint16_t>(p, in_kind, s) : dispatch_stem<f16_t>(p, in_kind, s);
 }
+
+#endif

@@ -20,7 +20,7 @@ int cft_check_launch(const char* what) {
   return CFT_OK;
 }
 
-extern "C" int cft_abi_version(void) { return 10; }   // 2: CFT_F16, dtype arguments of cft_bottleneck / cft_focus_conv, cft_to_nhwc; 3: w2_stages; 4: round 3 (probe exports removed, w2_stages required, permuted-row weights); 5: cft_clock_probe; 6: cft_gpt_upsample_add2, per-thread conv variant; 7: cft_conv2d_chain; 8: cft_conv2d_chain_ok takes ldx / ldy (the launcher's own validation); 9: cft_conv2d_chain_res, cft_linear_splitk, cft_layernorm_reduce; 10: cft_stem
+extern "C" int cft_abi_version(void) { return 11; }   // 2: CFT_F16, dtype arguments of cft_bottleneck / cft_focus_conv, cft_to_nhwc; 3: w2_stages; 4: round 3 (probe exports removed, w2_stages required, permuted-row weights); 5: cft_clock_probe; 6: cft_gpt_upsample_add2, per-thread conv variant; 7: cft_conv2d_chain; 8: cft_conv2d_chain_ok takes ldx / ldy (the launcher's own validation); 9: cft_conv2d_chain_res, cft_linear_splitk, cft_layernorm_reduce; 10: cft_stem; 11: cft_stem / cft_stem_ok removed (probe build only), cft_set_conv_variant 96 / 961-964 / 97
 
 extern "C" const char* cft_last_error(void) { return g_err; }
 

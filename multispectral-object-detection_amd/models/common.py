@@ -99,22 +99,6 @@ class PendingConv(_Pending):
         return torch.Size((B, self.conv.conv.out_channels, (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1))
 
 
-class PendingFocus(_Pending):
-    """Output of a ``Focus`` whose only reader is a ``Conv`` that is itself handed to the ``C3`` behind it (``Model.chain_plan``): that C3 runs
-    all three as ONE kernel (``ops.stem``) when the widths allow it, and neither the Focus output nor the Conv's output ever exists."""
-
-    def __init__(self, focus, img, dtype):
-        self.focus, self.img, self.dtype = focus, img, dtype
-
-    def materialize(self):
-        return self.focus(self.img)
-
-    @property
-    def shape(self):
-        B, _, H, W = self.img.shape
-        return torch.Size((B, self.focus.conv.conv.out_channels, H // 2, W // 2))
-
-
 def resolve(x):
     return x.materialize() if isinstance(x, _Pending) else x
 
@@ -264,15 +248,6 @@ class C3(_Packed):
         if _act_code(self.cv1.act) != _act_code(self.cv2.act):
             raise NotImplementedError("C3.cv1 and C3.cv2 must share an activation")
         cat = None
-        if isinstance(x, PendingConv) and isinstance(x.x, PendingFocus) and not self.training:
-            # Focus + Conv + this C3's cv1|cv2 as one kernel (the stem of a backbone): straight from the image
-            pf, conv = x.x, x.conv
-            dev = pf.img.device
-            pkf, pk1, pk2 = pf.focus._packed(pf.dtype, dev), conv._packed(pf.dtype, dev), self._packed(pf.dtype, dev)
-            if (_act_code(pf.focus.conv.act) == ACT_SILU and _act_code(conv.act) == ACT_SILU and ops.stem_ok(pf.img, pkf, pk1, pk2, pf.dtype)):
-                cat = ops.stem(pf.img, pkf, pk1, pk2, _act_code(self.cv1.act), pf.dtype)
-            else:
-                x = PendingConv(conv, pf.materialize())
         if cat is None and isinstance(x, PendingConv) and not self.training:      # the Conv in front of this C3 was left to it: one kernel for both
             src, conv = resolve(x.x), x.conv
             pk1 = conv._packed(src.dtype, src.device)

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .common import (GPT, NMS, SPP, Add, Add2, Bottleneck, C3, Concat, Conv, Focus, PendingBilinear, PendingConv, PendingFocus, Upsample, _Packed, autoShape, resolve,
+from .common import (GPT, NMS, SPP, Add, Add2, Bottleneck, C3, Concat, Conv, Focus, PendingBilinear, PendingConv, Upsample, _Packed, autoShape, resolve,
                      ACT_NONE, invalidate_packed)
 
 logger = logging.getLogger(__name__)
@@ -359,9 +359,6 @@ class Model(nn.Module):
             self.__dict__.get("_graphs", {}).clear()
         return property(get, set_, doc=doc)
 
-    fuse_stem = _switch("fuse_stem", False, "Opt-in: run Focus + the stride-2 Conv + the following C3's cv1|cv2 as ONE kernel (ops.stem, yolov5l widths). Bit-identical; "
-                        "-7 % HBM traffic per forward (the 839-MB Focus tensor per stream never exists) but no time: 943 us per launch against 313 + 463 us, "
-                        "-1 % pairs/s (profiles/r05_stem.md) - hence off by default.")
     fuse_cft_outputs = _switch("fuse_cft_outputs", True, "Run the two Add2 layers behind a GPT block and the Add that sums them as one kernel (cft_fusion_plan).")
     plan_concats = _switch("plan_concats", True, "Let Conv / C3 / Add layers that feed a head Concat write straight into their slice of its buffer (concat_plan).")
     depth_first = _switch("depth_first", None,
@@ -527,11 +524,6 @@ class Model(nn.Module):
         Conv and not to the C3 that would otherwise run it."""
         if m.f == -4 or (m.i == 0 and isinstance(m, Focus)):
             img = x2 if m.f == -4 else x
-            if (chain and self.fuse_stem and self.chain_convs and cbufs is not None and not self.training and isinstance(m, Focus)
-                    and (m.i + 1) in self.chain_plan() and isinstance(img, torch.Tensor) and img.is_cuda):
-                dt = m.compute_dtype or m.conv.conv.weight.dtype
-                if dt in (torch.bfloat16, torch.float16):
-                    return PendingFocus(m, img, dt)       # left to the C3 two rows down: Focus + Conv + cv1|cv2 as one kernel (ops.stem)
             return m(img)
         tgt = self.concat_plan().get(m.i) if cbufs is not None else None
         if tgt is not None:
@@ -552,7 +544,7 @@ class Model(nn.Module):
         if cbufs is not None and isinstance(m, Concat) and m.i in cbufs:
             return m(x, out=cbufs[m.i])
         if (chain and cbufs is not None and not self.training and m.i in self.chain_plan() and self.chain_convs
-                and isinstance(x, (torch.Tensor, PendingFocus)) and x.dtype in (torch.bfloat16, torch.float16)):
+                and isinstance(x, torch.Tensor) and x.dtype in (torch.bfloat16, torch.float16)):
             return PendingConv(m, x)                 # left to the C3 behind it (one kernel for the conv and the C3's cv1|cv2)
         return m(x)
 
@@ -575,9 +567,6 @@ class Model(nn.Module):
         cbufs = {} if (x.is_cuda and self.plan_concats) else None   # planned concat buffers of this walk
         # depth-first prefix (Model.depth_first): {first row: (i0, i1)} and the rows a segment covers
         seg_at, seg_rows, df = {}, set(), self.depth_first
-        if df and self.fuse_stem:
-            raise ValueError("Model.depth_first and Model.fuse_stem exclude each other: a depth-first segment runs its Focus row on its own "
-                             "(the one-kernel stem would be silently skipped on the rows the segment covers)")
         if df and x.is_cuda and not self.training and not profile and cbufs is not None and x.shape[0] >= 2 * int(df[0]) > 0:
             for sg in self.prefix_segments(df[1] if len(df) > 1 else None):
                 seg_at[sg[0]] = sg

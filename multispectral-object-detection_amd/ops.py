@@ -528,60 +528,6 @@ def focus_conv(img, pk, act, dtype):
     return out
 
 
-def _stem_image(img):
-    """The image layout cft_stem / cft_focus_conv read: contiguous rows, even strides and an even base address."""
-    es = img.element_size()
-    if img.stride(3) != 1 or any(img.stride(i) % 2 for i in range(3)) or img.data_ptr() % (2 * es):
-        img = img.contiguous()
-    return img
-
-
-def stem_ok(img, pkf, pk1, pk2, dtype):
-    """True when ``stem`` runs Focus (``pkf``) + the stride-2 Conv (``pk1``) + the pointwise layer (``pk2``) on the image batch ``img`` as the
-    single cft_stem kernel (yolov5l widths: 64 / 128 / <= 128 channels, 16-bit compute, fp32 / uint8 images or fp16 images with fp16 compute)."""
-    if not (isinstance(img, torch.Tensor) and img.is_cuda and img.dim() == 4 and img.shape[1] == 3 and dtype in (torch.bfloat16, torch.float16)):
-        return False
-    if not (img.dtype in (torch.uint8, torch.float32) or (img.dtype == torch.float16 and dtype == torch.float16)):
-        return False
-    if pkf.k != 3 or pkf.s != 1 or pkf.cin != 16 or pk1.k != 3 or pk1.s != 2 or pk1.cin != pkf.n or pk1.n_valid != pk1.n:
-        return False
-    if pk2.k != 1 or pk2.s != 1 or pk2.cin != pk1.n or pk2.kpad != pk1.n:
-        return False
-    B, _, H, W = img.shape
-    if B * ((H // 2 - 1) // 2 + 1) * ((W // 2 - 1) // 2 + 1) * pk2.n >= 2 ** 31:
-        return False
-    return bool(_lib.load().cft_stem_ok(H, W, pkf.n, pkf.kpad, pk1.n, pk1.kpad, pk2.n, _dt(dtype)))
-
-
-def stem(img, pkf, pk1, pk2, act2, dtype, out=None):
-    """act2(conv1x1(SiLU(conv3x3s2(SiLU(focus_conv(img)))))) as ONE kernel (cft_stem): neither the Focus output nor the stride-2 conv's output
-    reaches HBM.  Bit-identical to ``conv2d_chain(focus_conv(img, pkf, SILU, dtype), pk1, pk2, act2)``."""
-    _require_cuda(img, "stem")
-    if not stem_ok(img, pkf, pk1, pk2, dtype):
-        raise ValueError("stem: not eligible (stem_ok)")
-    img = _stem_image(img)
-    B, _, H, W = img.shape
-    Ho, Wo = (H // 2 - 1) // 2 + 1, (W // 2 - 1) // 2 + 1
-    if out is None:
-        out = new_nhwc(B, Ho, Wo, pk2.n, dtype, img.device)
-    if tuple(out.shape) != (B, pk2.n, Ho, Wo) or out.dtype != dtype:
-        raise ValueError(f"stem: out has shape {tuple(out.shape)}, expected {(B, pk2.n, Ho, Wo)}")
-    u8 = img.dtype == torch.uint8
-    kind = 1 if u8 else (2 if img.dtype == torch.float16 else 0)
-    lib = _lib.load()
-    args = (img.data_ptr(), kind, img.stride(0), img.stride(1), img.stride(2), 1.0 / 255.0 if u8 else 1.0,
-            pkf.w.data_ptr(), pkf.kpad, pkf.bias.data_ptr() if pkf.bias is not None else None,
-            pk1.w.data_ptr(), pk1.kpad, pk1.bias.data_ptr() if pk1.bias is not None else None,
-            pk2.w.data_ptr(), pk2.bias.data_ptr() if pk2.bias is not None else None,
-            out.data_ptr(), _view_ld(out, "stem out"), 0, B, H, W, pkf.n, pk1.n, pk2.n, act2, _dt(dtype), _stream())
-    rows_f, rows = B * (H // 2) * (W // 2), B * Ho * Wo
-    abytes = img.numel() * img.element_size() + rows * pk2.n_valid * 2 + (pkf.w.numel() + pk1.w.numel() + pk2.w.numel()) * 2
-    st = _timed(f"conv_stem_k3s2_n{pk1.n}_K{pkf.kpad}+{pk1.kpad}+{pk2.kpad}",
-                rows_f * pkf.flops_per_row + rows * (pk1.flops_per_row + pk2.flops_per_row), abytes, lambda: lib.cft_stem(*args))
-    _lib.check(st, "cft_stem")
-    return out
-
-
 def spp_maxpool(buf, C, ks):
     """In-place: buf [B,4C,H,W] NHWC, channels [0,C) already hold x; fills the three pooled slices."""
     _require_cuda(buf, "spp_maxpool")

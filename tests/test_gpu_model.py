@@ -590,7 +590,6 @@ def test_conv_c3_chain_is_bit_identical_to_the_layerwise_walk(dev, dtype):
     from msod_amd.utils.seeded import seeded_inputs
     cfg, model, sd = _seeded("cfg3", 3)
     model = model.to(dev).set_compute_dtype(dtype)
-    model.fuse_stem = True                           # opt-in (default off: no faster than its two kernels, profiles/r05_stem.md)
     assert model.chain_plan() == frozenset({1, 3, 6, 8, 13, 15})
     rgb, ir = seeded_inputs(2, 192, 256, 3)
     x, x2 = rgb.to(dev), ir.to(dev)
@@ -610,27 +609,23 @@ def test_conv_c3_chain_is_bit_identical_to_the_layerwise_walk(dev, dtype):
             model.chain_convs = False
             pred_u, raw_u = model.forward_once(x, x2)
             model.chain_convs = True
-            model.fuse_stem = False                      # Focus on its own, the chains stay
-            pred_ns, _ = model.forward_once(x, x2)
-            model.fuse_stem = True
-            pred_u8 = model.forward_once((x * 255).round().to(torch.uint8), (x2 * 255).round().to(torch.uint8))[0]      # uint8 images through the stem
-            model.fuse_stem = False
-            pred_u8_ns = model.forward_once((x * 255).round().to(torch.uint8), (x2 * 255).round().to(torch.uint8))[0]
-            model.fuse_stem = True
+            pred_u8 = model.forward_once((x * 255).round().to(torch.uint8), (x2 * 255).round().to(torch.uint8))[0]      # uint8 images, chained
+            model.chain_convs = False
+            pred_u8_u = model.forward_once((x * 255).round().to(torch.uint8), (x2 * 255).round().to(torch.uint8))[0]
+            model.chain_convs = True
             model.capture(2, 192, 256)
             pred_g = model(x, x2)[0].clone()
         torch.cuda.synchronize()
     finally:
         ops.CHAIN_RES_MIN_ROWS = monkey_rows
     # rows 1-2, 3-4 (RGB), 6-7, 8-9 (IR); and inside the two 256-channel C3s of the head (no shortcuts) cv2[j] + cv1[j + 1], j = 0, 1
-    # rows 0-2 / 5-7: Focus + Conv + cv1|cv2 as the one-kernel stem; rows 3-4 / 8-9: Conv + cv1|cv2 chained
-    assert sum(1 for rec in log if rec[0].startswith("conv_stem")) == 2 and not any(rec[0].startswith("conv_focus") for rec in log)
-    assert sum(1 for rec in log if rec[0].startswith("conv_chain_k3s2")) == 2 and sum(1 for rec in log if rec[0].startswith("conv_chain_k3s1")) == 4
+    assert sum(1 for rec in log if rec[0].startswith("conv_focus")) == 2
+    assert sum(1 for rec in log if rec[0].startswith("conv_chain_k3s2")) == 4 and sum(1 for rec in log if rec[0].startswith("conv_chain_k3s1")) == 4
     # rows 14 / 16: the 256-channel C3s WITH shortcuts (n = 9): cv2[j] (+ shortcut) and cv1[j + 1] as one launch, j = 0..7, per stream
     assert sum(1 for rec in log if rec[0].startswith("conv_chainres_k3s1_n256")) == 16
     assert sum(1 for rec in log if rec[0] == "conv_k1s1_n256_K256") <= 7       # (was 23: 18 of them were Bottleneck cv1 launches; 2 remain)
     assert torch.equal(pred_c, pred_u) and torch.equal(pred_c2, pred_u) and torch.equal(pred_g, pred_u)
-    assert torch.equal(pred_ns, pred_u) and torch.equal(pred_u8, pred_u8_ns)
+    assert torch.equal(pred_u8, pred_u8_u)
     assert all(torch.equal(a, b) for a, b in zip(raw_c, raw_u))
 
 

@@ -255,40 +255,6 @@ def test_conv2d_chain_is_bit_identical_to_two_launches(dev, dtype, B, H, W, cin,
         ops.conv2d_chain(x, pk_bad, pk2_bad, ops.ACT_SILU)
 
 
-@pytest.mark.parametrize("dtype,img_dtype", [(torch.bfloat16, torch.float32), (torch.bfloat16, torch.uint8), (torch.float16, torch.float16), (torch.float16, torch.float32)],
-                         ids=["bf16-f32img", "bf16-u8img", "fp16-f16img", "fp16-f32img"])
-@pytest.mark.parametrize("B,H,W,n2,act2", [(2, 640, 640, 128, 1), (3, 96, 128, 128, 1), (1, 160, 224, 64, 0), (2, 72, 100, 128, 1), (5, 32, 32, 128, 1), (1, 36, 44, 8, 1)])
-def test_stem_is_bit_identical_to_focus_then_the_chained_conv(dev, dtype, img_dtype, B, H, W, n2, act2):
-    """cft_stem - Focus + Conv(64 -> 128, 3x3, stride 2) + the pointwise layer behind it in one persistent kernel, straight from the image:
-    the Focus output and the conv output stay in LDS (8 x 8-pixel tiles).  Same products, k chunks, order and roundings as cft_focus_conv followed by
-    cft_conv2d_chain -> bit-identical, for full tiles (640 x 640), partial tiles in both directions (Ho = 18 / 25 / 9 rows, Wo = 25 / 11
-    columns), more tiles than CUs and fewer, one tile, fp32 / uint8 / fp16 images, a narrow second layer, no activation, a channel-slice
-    destination."""
-    from msod_amd import ops
-    g = torch.Generator().manual_seed(61)
-    img = torch.rand((B, 3, H, W), generator=g)
-    if img_dtype == torch.uint8:
-        img = (img * 255).round().to(torch.uint8)
-    img = img.to(dev).to(img_dtype)
-    pkf = ops.pack_conv(_rnd(64, 12, 3, 3, seed=62) * (2.0 / 108) ** 0.5, _rnd(64, seed=63) * 0.1, dtype, cin_pad=16, device=dev)
-    pk1 = ops.pack_conv(_rnd(128, 64, 3, 3, seed=64) * (2.0 / 576) ** 0.5, _rnd(128, seed=65) * 0.1, dtype, s=2, device=dev)
-    pk2 = ops.pack_conv(_rnd(n2, 128, 1, 1, seed=66) * (2.0 / 128) ** 0.5, _rnd(n2, seed=67) * 0.1, dtype, device=dev)
-    assert ops.stem_ok(img, pkf, pk1, pk2, dtype)
-    f = ops.focus_conv(img, pkf, ops.ACT_SILU, dtype)
-    two = ops.conv2d_chain(f, pk1, pk2, act2)
-    one = ops.stem(img, pkf, pk1, pk2, act2, dtype)
-    torch.cuda.synchronize()
-    assert one.shape == two.shape and torch.equal(one, two) and float(two.float().abs().max()) > 0.05
-    Ho, Wo = two.shape[2], two.shape[3]
-    buf = ops.new_nhwc(B, Ho, Wo, pk2.n + 24, dtype, dev)
-    buf.zero_()
-    ops.stem(img, pkf, pk1, pk2, act2, dtype, out=buf[:, 16:16 + pk2.n])
-    torch.cuda.synchronize()
-    assert torch.equal(buf[:, 16:16 + pk2.n], two) and float(buf[:, :16].float().abs().max()) == 0.0 and float(buf[:, 16 + pk2.n:].float().abs().max()) == 0.0
-    pk1_bad = ops.pack_conv(_rnd(64, 64, 3, 3, seed=68), None, dtype, s=2, device=dev)               # yolov5s widths: the separate kernels' domain
-    assert not ops.stem_ok(img, pkf, pk1_bad, ops.pack_conv(_rnd(64, 64, 1, 1, seed=69), None, dtype, device=dev), dtype)
-
-
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("B,H,W,k,n2", [(2, 40, 40, 3, 256), (1, 19, 23, 3, 256), (3, 16, 16, 3, 64), (1, 40, 40, 1, 256), (64, 40, 40, 3, 256)])
 def test_conv2d_chain_res_is_bit_identical_to_two_launches(dev, dtype, B, H, W, k, n2):

@@ -381,8 +381,8 @@ def test_prefix_segments_and_executor_switches():
     assert m.prefix_segments() == [(0, 4), (5, 9)] and m.prefix_segments(3) == [(0, 2), (5, 7)] and m.prefix_segments(2) == []
     assert Model(named_config("cfg1")).prefix_segments() == [(0, 4), (10, 14)]            # add-fusion: row 4 is also read by the Add
     assert Model(named_config("yolov5l_fusion_transformer_FLIR")).prefix_segments() == [(0, 2), (3, 5)]   # 4-GPT layout: GPT after P2
-    assert (m.depth_first, m.fuse_stem, m.splitk, m.chain_convs, m.fuse_cft_outputs, m.plan_concats) == (None, False, True, True, True, True)
-    for name, value in (("depth_first", (8, None)), ("fuse_stem", True), ("splitk", False), ("chain_convs", False),
+    assert (m.depth_first, m.splitk, m.chain_convs, m.fuse_cft_outputs, m.plan_concats) == (None, True, True, True, True)
+    for name, value in (("depth_first", (8, None)), ("splitk", False), ("chain_convs", False),
                         ("fuse_cft_outputs", False), ("plan_concats", False)):
         m._graphs["sentinel"] = object()
         setattr(m, name, value)
