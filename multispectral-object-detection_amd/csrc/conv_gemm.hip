@@ -600,7 +600,8 @@ static int dispatch_conv(const ConvParams& p, hipStream_t stream) {
   // the hand-scheduled 8-wave kernel (conv_gemm_asm.hip: bit-identical, K loop at 1.27 instead of 1.5 us per 256-row step) from 12 K steps on (below that
   // the 16-wave kernel's shorter prologue + epilogue outweigh the loop, profiles/r06_asm_kloop.md), its tile height picked so that the tile count
   // fills whole rounds of the CUs; variant 97: the round-5 choice
-  if (wide_ok && g_conv_variant != 97 && p.Kpad >= 12 * 64 && p.ksplit <= 1 && conv_asm_ok(p, dtype_code<T>())) {
+  static const int asm_min_steps = [] { const char* e = getenv("CFT_ASM_MIN_STEPS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 12; }();   // (tuning knob)
+  if (wide_ok && g_conv_variant != 97 && p.Kpad >= asm_min_steps * 64 && p.ksplit <= 1 && conv_asm_ok(p, dtype_code<T>())) {
     const int tile = conv_asm_choose(p);
     if (tile >= 0) return conv_asm_launch(p, dtype_code<T>(), tile, stream);
   }
