@@ -364,7 +364,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run both backbones on one HIP stream")
     ap.add_argument("--sustained-steps", type=int, default=500, help="extra >= 10 s leg at N = 1 (0 = skip)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed configuration")
-    ap.add_argument("--in-flight", type=int, default=3, help="forwards in flight (own graphs, buffers and streams each); 1 = one at a time")
+    ap.add_argument("--in-flight", type=int, default=0, help="forwards in flight (own graphs, buffers and streams each); 1 = one at a time; 0 (default) = 3 from 32 pairs "
+                    "per GPU on, 4 below (8 pairs: 2 719 pairs/s with 4, 2 553 with 3, 2 360 with the rounds-3-5 mode: profiles/r06_forwards_in_flight.txt)")
     ap.add_argument("--fly-two-streams", action="store_true", help="A/B: the forwards in flight keep their two backbone streams (rounds 3-5 ran 2 such forwards); "
                     "by default, from 3 in flight on, each forward in flight is captured on ONE stream (no stream-group lottery: profiles/r06_forwards_in_flight.txt) "
                     "and the two-stream graph serves the one-at-a-time leg")
@@ -415,6 +416,8 @@ def main():
     rgb, ir = rgb.to(dev), ir.to(dev)
 
     log("weights loaded, packing + capturing")
+    if args.in_flight <= 0:
+        args.in_flight = 3 if args.batch >= 32 else 4
     k_fly = 1 if args.no_graph else max(1, args.in_flight)
     fly_single = False
     with torch.no_grad():
