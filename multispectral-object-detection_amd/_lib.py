@@ -13,7 +13,7 @@ import subprocess
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcft_hip.so")
+LIB_PATH = os.environ.get("CFT_HIP_LIB") or os.path.join(_HERE, "libcft_hip.so")      # (CFT_HIP_LIB: experiments with an alternative build, e.g. the probe library)
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ("runtime.hip", "conv_gemm.hip", "conv_gemm_asm.hip", "focus_conv.hip", "bottleneck.hip", "pointwise.hip", "attention.hip", "nms.hip", "train.hip")
 

@@ -41,9 +41,17 @@ QUAD = [92, 96]  # s[92:95] / s[96:99]
 OOB = "%[voob]"   # a VGPR holding 0x80000000 (a literal beside vcc violates the constant-bus limit)
 
 
+PAD_NOPS = int(os.environ.get("CONV_ASM_PAD_NOPS", "0"))     # experiment (profiles/r06_asm_kloop.md section 5): idle issue slots after every MFMA - same work, more cycles
+
+
 def mfma(op, i, j, h):
     a = 4 * (4 * i + j)
-    return f"{op} a[{a}:{a+3}], v[{FA[h]+4*i}:{FA[h]+4*i+3}], v[{FB[h]+4*j}:{FB[h]+4*j+3}], a[{a}:{a+3}]"
+    m = f"{op} a[{a}:{a+3}], v[{FA[h]+4*i}:{FA[h]+4*i+3}], v[{FB[h]+4*j}:{FB[h]+4*j+3}], a[{a}:{a+3}]"
+    n = PAD_NOPS
+    while n > 0:
+        m += "\\n\\t" + f"s_nop {min(n, 16) - 1}"
+        n -= 16
+    return m
 
 
 def reads(h, c, mt=8):
