@@ -181,6 +181,8 @@ bool conv_asm_ok(const ConvParams& p, int dtype);
 int conv_asm_choose(const ConvParams& p);            // tile index whose tile count fills the CUs' rounds best, -1: too few tiles for any
 int conv_asm_tile_rows(int tile);
 int conv_asm_launch(const ConvParams& p, int dtype, int tile, hipStream_t stream);
+bool conv_asm_chain_ok(const ConvParams& p, int dtype);   // the chained pair with a 256-channel first layer (p.w2 / bias2 / N2 [/ res / y1] set)
+int conv_asm_chain_launch(const ConvParams& p, int dtype, hipStream_t stream);
 
 // conv_ring.hip: launch the ring kernel (dtype CFT_BF16 / CFT_F16; ablate: timing probes of -DCFT_PROBES builds, 0 otherwise)
 int conv_ring_launch(const ConvParams& p, int dtype, int ablate, hipStream_t stream);

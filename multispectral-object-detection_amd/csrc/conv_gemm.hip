@@ -680,6 +680,8 @@ template <typename T>
 static int dispatch_chain(const ConvParams& p, hipStream_t stream) {
   if constexpr (sizeof(T) == 2) {
     if (p.N == 128) return launch_conv<T, 192, 128, 2, 4, true, 0, true, true>(p, stream);   // two workgroups per CU (80 KiB)
+    // 256-channel first layer: the 8-wave kernel with the hand-scheduled first K loop (conv_gemm_asm.hip; variant 97: the 16-wave chained kernel)
+    if (g_conv_variant != 97 && conv_asm_chain_ok(p, dtype_code<T>())) return conv_asm_chain_launch(p, dtype_code<T>(), stream);
     if (p.y1 != nullptr) return launch_conv<T, 256, 256, 4, 4, true, 0, true, true, true>(p, stream);   // + shortcut (cft_conv2d_chain_res)
     return launch_conv<T, 256, 256, 4, 4, true, 0, true, true>(p, stream);                   // 16 waves, all 160 KiB
   } else return CFT_EINVAL;

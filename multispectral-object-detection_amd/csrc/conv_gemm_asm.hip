@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(512) conv_gemm_asm_kernel(const ConvAsmParams 
   // Only voffset is range-checked, so the input SRD starts `abias` bytes BELOW the tensor (the most negative tap of a border pixel) and every
   // voffset carries + abias.
   constexpr uint32_t OOB = 0x80000000u;
-  const long abias = ((long)p.W + 1) * p.ldx * ES;
+  const long abias = ((long)p.pad * p.W + p.pad) * p.ldx * ES;      // the most negative tap of a border pixel: pad rows up, pad pixels left
   uint32_t voa[4], vob[4], am[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -295,6 +295,219 @@ __global__ void __launch_bounds__(512) conv_gemm_asm_kernel(const ConvAsmParams 
 #undef CONV_ASM_EPI
 }
 
+// ------------------------------------------------------------------------------------ the chained pair on the asm K loop
+// conv_gemm_kernel<..., CHAIN, CRES> (conv_gemm.hip) with the hand-scheduled first K loop: a 256-channel first layer (a Bottleneck's 3x3, reference
+// models/common.py:99-109, or the stride-2 Conv in front of a C3) whose 256 x 256 tile - after bias + SiLU (+ the shortcut, added in fp32 before the one
+// rounding, :108) - is written to LDS AS the A operand of a pointwise second GEMM (the next Bottleneck's cv1 / the C3's cv1|cv2, N2 <= 256): four
+// 64-channel images of 256 rows x 128 B in the dead staging buffers, the second layer's weights streaming through one extra 32-KiB buffer and the images
+// already consumed.  With a shortcut the finished images are also stored to y1 (the next shortcut).  Same values, same roundings, same k order as the two
+// launches and as the 16-wave chained kernel: bit-identical (tests/test_gpu_ops.py: the chain tests).  Wave (wm, wn) owns rows 128 wm .., columns 64 wn .. of
+// the first layer's tile: its accumulators ARE image wn.
+#define CONV_ASM_CHAIN2_STMT(text_)                                                                                        \
+  asm volatile(text_ : : [ca0] "v"(ca[0]), [ca1] "v"(ca[1]), [cb0] "v"(cb[0]), [cb1] "v"(cb[1]) : CONV_ASM_CLOBBERS)
+
+template <typename T>
+__global__ void __launch_bounds__(512) conv_gemm_asm_chain_kernel(const ConvAsmParams ap) {
+  static_assert(sizeof(T) == 2, "16-bit operand types only");
+  constexpr int BM = 256, GE = 8, ES = 2, MT0 = 8, MT1 = 8;
+  constexpr bool MASKED = true;
+  constexpr int IMG = 32768;                                     // one 64-channel image: 256 rows x 128 B
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const ConvParams& p = ap.p;
+
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, slot = bid >> 3;
+  const int tm = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;          // one N tile: the logical tile index is the M tile
+  const int m0 = tm * BM, n0 = 0;
+
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int rs0 = tid0 >> 3;
+  const int g0 = (tid0 & 7) ^ (rs0 & 7);
+
+  constexpr uint32_t OOB = 0x80000000u;
+  const long abias = ((long)p.pad * p.W + p.pad) * p.ldx * ES;      // the most negative tap of a border pixel: pad rows up, pad pixels left
+  uint32_t voa[4], vob[4], am[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + rs0 + i * 64;
+    int a_off = 0;
+    uint32_t mk = 0;
+    if (m < p.M) {
+      const int t = fast_div(m, p.wo_mul, p.wo_sh);
+      const int wo = m - t * p.Wo;
+      const int b = fast_div(t, p.ho_mul, p.ho_sh);
+      const int ho = t - b * p.Ho;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      a_off = ((b * p.H + hi0) * p.W + wi0) * p.ldx + p.xoff;
+      uint32_t wbits = 0;
+      for (int kw = 0; kw < p.KS; ++kw) wbits |= ((unsigned)(wi0 + kw) < (unsigned)p.W ? 1u : 0u) << kw;
+      for (int kh = 0; kh < p.KS; ++kh)
+        if ((unsigned)(hi0 + kh) < (unsigned)p.H) mk |= wbits << (kh * p.KS);
+    }
+    am[i] = mk;
+    voa[i] = (uint32_t)(((long)a_off + g0 * GE) * ES + abias);
+    const int n = rs0 + i * 64;
+    vob[i] = (n < p.N) ? (uint32_t)(((long)n * p.Kpad + g0 * GE) * ES) : OOB;
+  }
+  const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.x) - abias, 0, (int)(p.x_bytes + abias), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  const uint32_t ldsk = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  const int lrow0 = lane0 & 15, lgrp0 = lane0 >> 4;
+  uint32_t ra[2], rb[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t rd = (uint32_t)(lrow0 * 128 + (((h * 4 + lgrp0) ^ (lrow0 & 7)) << 4));
+    ra[h] = ldsk + (uint32_t)(wm * MT0 * 16 * 128) + rd;
+    rb[h] = ldsk + 65536u + wn * 8192u + rd;
+  }
+  const uint32_t wb = ldsk + (uint32_t)wave * 1024u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long tab = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ConvAsmParams, table);
+#else
+  const unsigned long long tab = 0;
+#endif
+  uint32_t toff = 0, cnt = (uint32_t)ap.npairs, m0s;
+  const uint32_t voob = OOB;
+  if constexpr (__is_same(T, f16_t)) { CONV_ASM_TILES(F16, MASK) } else { CONV_ASM_TILES(BF16, MASK) }
+  __builtin_amdgcn_s_barrier();                          // every wave's requests have landed and its reads returned: all four staging buffers are free
+
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __attribute__((address_space(4))) ConvParams* kp = (const __attribute__((address_space(4))) ConvParams*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  const ConvParams pe = *kp;
+#else
+  const ConvParams& pe = p;
+#endif
+  const bool with_res = pe.y1 != nullptr;                // uniform
+  // (every per-lane value of the phases below is re-derived from the thread id HERE: computed before the K loop they would not fit beside its operands and spill)
+  int tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));
+  const int lane = tid2 & 63, rs = tid2 >> 3, g = (tid2 & 7) ^ (rs & 7), lrow = lane & 15, lgrp = lane >> 4, tid = tid2;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  float bias_v[4];
+  conv_load_bias<64>(pe, 0, wn, lane, bias_v);             // (the first layer's bias: an L2 hit; loaded here for the same reason)
+  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(cft_zero_page);
+  unsigned char* sX = smem + 4 * IMG;                    // the extra weight buffer behind the four images
+  auto load_w2 = [&](int k2, unsigned char* dst) {      // second layer's weights [N2][256], K step k2 -> dst, in the staging pattern of the K loop
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = rs + i * 64;
+      const unsigned char* src = (n < pe.N2) ? pe.w2 + ((long)n * pe.N + k2 * 64 + g * GE) * ES : zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + i * 8192 + wave * 1024), 16, 0, 0);
+    }
+  };
+  if (with_res) {                                        // the shortcut tile -> the image area, in the image layout; rows beyond M read the zero page
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + rs + i * 64;
+        const unsigned char* src = (m < pe.M) ? pe.res + ((long)m * pe.ldr + pe.roff + k2 * 64 + g * GE) * ES : zero_page;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(smem + k2 * IMG + i * 8192 + wave * 1024), 16, 0, 0);
+      }
+  }
+  load_w2(0, sX);
+  float bias2_v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = wn * 64 + j * 16 + lrow;
+    bias2_v[j] = (pe.bias2 != nullptr && n < pe.N2) ? pe.bias2[n] : 0.0f;
+  }
+  // first layer's bias + SiLU (+ shortcut) + rounding on the accumulators -> image wn; lanes l / l ^ 1 hold neighbouring channels of the same four
+  // pixels and swap half of their values by DPP so that each writes two packed channel PAIRS (even lane: pixels 0, 1; odd: 2, 3)
+  const bool odd = lane & 1;
+  unsigned char* img = smem + wn * IMG;
+  if (with_res) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // the shortcut tile (and W2 step 0) landed, visible to every wave
+  }
+  asm_static_for<8>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    asm_static_for<4>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const f32x4_t t = agpr_tile<i * 4 + j>();
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = apply_act<CFT_ACT_SILU>(t[e] + bias_v[j]);
+      const int row = wm * 128 + i * 16 + lgrp * 4 + (odd ? 2 : 0);
+      const int c = j * 16 + (lrow & 14);                // channel inside this wave's 64-channel image
+      uint32_t* pa = reinterpret_cast<uint32_t*>(img + (c & 7) * 2 + row * 128 + (((c >> 3) ^ (row & 7)) << 4));
+      uint32_t* pb = reinterpret_cast<uint32_t*>(img + (c & 7) * 2 + (row + 1) * 128 + (((c >> 3) ^ ((row + 1) & 7)) << 4));
+      if (with_res) {
+        const float ga = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(odd ? v[0] : v[2]), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        const float gb = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(odd ? v[1] : v[3]), 0xB1, 0xF, 0xF, true));
+        float lo0 = odd ? ga : v[0], hi0 = odd ? v[2] : ga;      // pixel A: channels c, c + 1
+        float lo1 = odd ? gb : v[1], hi1 = odd ? v[3] : gb;      // pixel B = A + 1
+        float r0l, r0h, r1l, r1h;
+        Elem<T>::unpack2(*pa, r0l, r0h);
+        Elem<T>::unpack2(*pb, r1l, r1h);
+        lo0 += r0l; hi0 += r0h; lo1 += r1l; hi1 += r1h;
+        *pa = Elem<T>::pack2(lo0, hi0);
+        *pb = Elem<T>::pack2(lo1, hi1);
+      } else {
+        const uint32_t r01 = Elem<T>::pack2(v[0], v[1]), r23 = Elem<T>::pack2(v[2], v[3]);
+        const uint32_t got = (uint32_t)__builtin_amdgcn_mov_dpp((int)(odd ? r01 : r23), 0xB1, 0xF, 0xF, true);
+        *pa = odd ? ((got & 0xffffu) | (r23 << 16)) : ((r01 & 0xffffu) | (got << 16));
+        *pb = odd ? ((got >> 16) | (r23 & 0xffff0000u)) : ((r01 >> 16) | (got & 0xffff0000u));
+      }
+    });
+  });
+  // image k2 IS a quarter of the first layer's output tile: with a shortcut it is stored to y1 as 16-byte granules (thread (rs, slot) holds granule
+  // slot ^ (row & 7) of its rows: eight consecutive threads write one full 128-byte line), issued right before the MFMA step that consumes the image; the
+  // barrier behind that step drains the stores, so an image is never overwritten (by a later W2 step) before it is on its way to memory
+  auto store_image = [&](int k2) {
+    if (with_res) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = rs + i * 64, m = m0 + row;
+        const gran_t t_ = *reinterpret_cast<const gran_t*>(smem + k2 * IMG + row * 128 + ((tid & 7) << 4));
+        if (m < pe.M) *reinterpret_cast<gran_t*>(pe.y1 + ((long)m * pe.ldy1 + pe.yoff1 + k2 * 64 + g * GE) * ES) = t_;
+      }
+    }
+  };
+  // second GEMM: four K steps = the four images; fragment bases of this wave: A rows 128 wm .. of image k2, B rows 64 wn .. of a weight buffer
+  const uint32_t rd0 = (uint32_t)(lrow * 128 + ((lgrp ^ (lrow & 7)) << 4));
+  const uint32_t abase = lds0 + (uint32_t)(wm * 16384) + rd0, bX = lds0 + 4u * IMG + wn * 8192u + rd0, bI = lds0 + wn * 8192u + rd0;
+  uint32_t ca[2], cb[2];
+#define CONV_ASM_CHAIN2_RUN(aimg_, bbase_)                                                                                 \
+  ca[0] = abase + (aimg_) * IMG; ca[1] = ca[0] ^ 64u; cb[0] = (bbase_); cb[1] = cb[0] ^ 64u;                               \
+  if constexpr (__is_same(T, f16_t)) { CONV_ASM_CHAIN2_STMT(CONV_ASM_CHAIN2_F16); } else { CONV_ASM_CHAIN2_STMT(CONV_ASM_CHAIN2_BF16); }
+  asm volatile(CONV_ASM_ZERO_ACC ::: CONV_ASM_CLOBBERS);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // images written, W2 step 0 in X
+  store_image(0);
+  CONV_ASM_CHAIN2_RUN(0, bX)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // X and image 0 are free (image 0 is in memory)
+  load_w2(1, sX);
+  load_w2(2, smem);
+  store_image(1);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // both landed
+  CONV_ASM_CHAIN2_RUN(1, bX)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // image 1 is free
+  load_w2(3, smem + IMG);                                // lands under step 2
+  store_image(2);
+  CONV_ASM_CHAIN2_RUN(2, bI)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  store_image(3);
+  CONV_ASM_CHAIN2_RUN(3, bI + IMG)
+#undef CONV_ASM_CHAIN2_RUN
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // every wave is past its last image read: the strips may overwrite the images
+  ConvParams p2 = pe;
+  p2.N = pe.N2;
+  p2.res = nullptr;
+  const int row0 = wm * 128;
+  if (p2.act == CFT_ACT_SILU) conv_epilogue_agpr<T, CFT_ACT_SILU, false, 8>(p2, smem, m0, 0, row0, wn, wave, lane, bias2_v);
+  else if (p2.act == CFT_ACT_GELU) conv_epilogue_agpr<T, CFT_ACT_GELU, false, 8>(p2, smem, m0, 0, row0, wn, wave, lane, bias2_v);
+  else conv_epilogue_agpr<T, CFT_ACT_NONE, false, 8>(p2, smem, m0, 0, row0, wn, wave, lane, bias2_v);
+}
+
 // ------------------------------------------------------------------------------------ host
 // Eligibility: 16-bit operands, the uniform K walk (Cin a multiple of the 64-wide K step, no K padding), the walk fits the table, the
 // buffer-addressing extents (masked granules are fetched at voffset 2^31, so both buffers must end below it), no split-K.
@@ -303,7 +516,7 @@ bool conv_asm_ok(const ConvParams& p, int dtype) {
   if (p.Cin % 64 != 0 || p.Kpad != p.K || p.KS > 5 || p.ksplit > 1) return false;
   const int nk = p.Kpad / 64;
   if (nk < 2 || ((nk + 1) & ~1) + 3 > ASM_MAXE) return false;
-  return p.x_bytes + 2L * ((long)p.W + 1) * p.ldx * 2 < (1L << 31) && p.w_bytes < (1L << 31);
+  return p.x_bytes + 2L * ((long)p.pad * p.W + p.pad) * p.ldx * 2 < (1L << 31) && p.w_bytes < (1L << 31);
 }
 
 template <typename T, bool MASKED, int MT0, int MT1>
@@ -322,6 +535,29 @@ static int launch_asm_tile(const ConvAsmParams& ap, int tile, int grid, hipStrea
     case 2: return launch_asm_t<T, MASKED, 7, 6>(ap, grid, stream);
     case 3: return launch_asm_t<T, MASKED, 6, 6>(ap, grid, stream);
     default: return launch_asm_t<T, MASKED, 4, 4>(ap, grid, stream);
+  }
+}
+
+// the K-walk table of a launch (and its step-pair count)
+static void fill_asm_table(ConvAsmParams& ap, const ConvParams& p) {
+  const int nk = p.Kpad / 64, nkp = (nk + 1) & ~1;
+  ap.npairs = nkp / 2;
+  // K order: conv_gemm_kernel's - tap-major (k = (kh, kw, ci): the channel chunks of a tap, then the next tap), or CHUNK-major for 3x3 layers
+  // with Cin >= 256 (all nine taps of a 64-channel chunk, then the next chunk: a tap re-reads the pixels its neighbour just read)
+  const bool chunk_major = p.KS == 3 && p.Cin >= 256 && p.K == 9 * p.Cin;
+  const int chunks = p.Cin / 64, taps = p.KS * p.KS;
+  for (int t = 0; t < nkp + 3; ++t) {
+    uint32_t* e = ap.table[t];
+    if (t < nk) {
+      const int tap = chunk_major ? t % taps : t / chunks, chunk = chunk_major ? t / taps : t % chunks;
+      const int kh = tap / p.KS, kw = tap - kh * p.KS;
+      e[0] = (uint32_t)((((long)kh * p.W + kw) * p.ldx + chunk * 64) * 2);
+      e[1] = (uint32_t)(((long)tap * p.Cin + chunk * 64) * 2);
+      e[2] = 1u << tap;
+    } else {            // beyond K: the odd-count padding step stages zeros (tap bit 0 -> every A granule out of range); later entries are requested, never used
+      e[0] = 0; e[1] = 0; e[2] = 0;
+    }
+    e[3] = 0;
   }
 }
 
@@ -363,28 +599,38 @@ int conv_asm_launch(const ConvParams& p, int dtype, int tile, hipStream_t stream
   const int tilesM = (p.M + bm - 1) / bm;
   ap.p.tilesN = (p.N + 255) / 256;
   ap.p.ksplit = 1;
-  const int nk = p.Kpad / 64, nkp = (nk + 1) & ~1;
-  ap.npairs = nkp / 2;
-  // K order: conv_gemm_kernel's - tap-major (k = (kh, kw, ci): the channel chunks of a tap, then the next tap), or CHUNK-major for 3x3 layers
-  // with Cin >= 256 (all nine taps of a 64-channel chunk, then the next chunk: a tap re-reads the pixels its neighbour just read)
-  const bool chunk_major = p.KS == 3 && p.Cin >= 256 && p.K == 9 * p.Cin;
-  const int chunks = p.Cin / 64, taps = p.KS * p.KS;
-  for (int t = 0; t < nkp + 3; ++t) {
-    uint32_t* e = ap.table[t];
-    if (t < nk) {
-      const int tap = chunk_major ? t % taps : t / chunks, chunk = chunk_major ? t / taps : t % chunks;
-      const int kh = tap / p.KS, kw = tap - kh * p.KS;
-      e[0] = (uint32_t)((((long)kh * p.W + kw) * p.ldx + chunk * 64) * 2);
-      e[1] = (uint32_t)(((long)tap * p.Cin + chunk * 64) * 2);
-      e[2] = 1u << tap;
-    } else {            // beyond K: the odd-count padding step stages zeros (tap bit 0 -> every A granule out of range); later entries are requested, never used
-      e[0] = 0; e[1] = 0; e[2] = 0;
-    }
-    e[3] = 0;
-  }
+  fill_asm_table(ap, p);
+  const int nk = p.Kpad / 64;
   const bool masked = p.KS > 1 || (nk & 1);
   ap.masked = masked;
   const int grid = tilesM * ap.p.tilesN;
   if (dtype == CFT_BF16) return masked ? launch_asm_tile<uint16_t, true>(ap, tile, grid, stream) : launch_asm_tile<uint16_t, false>(ap, tile, grid, stream);
   return masked ? launch_asm_tile<f16_t, true>(ap, tile, grid, stream) : launch_asm_tile<f16_t, false>(ap, tile, grid, stream);
+}
+
+// The chained pair (cft_conv2d_chain / cft_conv2d_chain_res with a 256-channel first layer) on the asm K loop: eligibility as conv_asm_ok + one N tile of 256
+// channels + at least 12 K steps; p carries w2 / bias2 / N2 (/ res, y1) as dispatch_chain passes them.
+bool conv_asm_chain_ok(const ConvParams& p, int dtype) {
+  return conv_asm_ok(p, dtype) && p.N == 256 && p.N2 > 0 && p.N2 <= 256 && p.Kpad >= 24 * 64;   // (18 steps - 3x3 s2 128 -> 256 - measured slower: 352 vs 336 us)
+}
+
+template <typename T>
+static int launch_asm_chain_t(const ConvAsmParams& ap, int grid, hipStream_t stream) {
+  constexpr int smem_bytes = 5 * 32768;
+  cft_allow_lds<&conv_gemm_asm_chain_kernel<T>>(smem_bytes);
+  hipLaunchKernelGGL((conv_gemm_asm_chain_kernel<T>), dim3(grid), dim3(512), smem_bytes, stream, ap);
+  return cft_check_launch("conv_gemm_asm_chain_kernel");
+}
+
+int conv_asm_chain_launch(const ConvParams& p, int dtype, hipStream_t stream) {
+  if (!conv_asm_chain_ok(p, dtype)) { cft_set_error("conv_gemm_asm_chain_kernel: layer pair not eligible"); return CFT_EINVAL; }
+  ConvAsmParams ap;
+  ap.p = p;
+  ap.p.tilesN = 1;
+  ap.p.ksplit = 1;
+  fill_asm_table(ap, p);
+  ap.masked = 1;
+  const int grid = (p.M + 255) / 256;
+  if (dtype == CFT_BF16) return launch_asm_chain_t<uint16_t>(ap, grid, stream);
+  return launch_asm_chain_t<f16_t>(ap, grid, stream);
 }

@@ -724,6 +724,7 @@ ASM_CASES = [
     (2, 9, 9, 512, 40, 3, 2, False),        # chunk-major, stride 2, N tail inside the first tile (72 steps)
     (1, 20, 20, 320, 256, 1, 1, True),      # pointwise with an odd step count (5): the masked form with the zero step
     (1, 7, 5, 128, 264, 1, 1, False),       # 35 rows: one ragged tile, two K steps (the shortest walk the kernel takes)
+    (2, 13, 17, 64, 256, 5, 2, False),      # 5x5, stride 2: 25 taps (odd step count), border taps two pixels out (the descriptor's head room is pad-aware)
 ]
 
 

@@ -22,6 +22,9 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
+    if os.environ.get("CFT_CHAIN_BENCH_VARIANT"):          # e.g. 97 = the round-5 kernels (16-wave chained kernel, 16-wave plain GEMMs)
+        from msod_amd import _lib
+        _lib.load().cft_set_conv_variant(int(os.environ["CFT_CHAIN_BENCH_VARIANT"]))
     if args.res:
         return res_pair(args, dev, g)
     # (input channels, first layer's width, input size = image size / div, stride): the two backbone pairs, and cv2 of Bottleneck j +

@@ -146,6 +146,25 @@ def loop_text(op, g, masked, mt=8, ap=4):
     return L
 
 
+def chain2_text(op):
+    """One K step (64 channels = one LDS image) of the chained kernel's SECOND GEMM: A fragments from the image at %[ca0] / %[ca1] (k half 0 / 1),
+    B fragments from the weight buffer at %[cb0] / %[cb1]; no staging inside (the caller streams the weights between the steps)."""
+    order = [(i, j) for i in range(8) for j in range(4)]
+    L = []
+    for j in range(4):
+        L.append(f"ds_read_b128 v[{FB[0]+4*j}:{FB[0]+4*j+3}], %[cb0] offset:{j*2048}")
+    for i in range(8):
+        L.append(f"ds_read_b128 v[{FA[0]+4*i}:{FA[0]+4*i+3}], %[ca0] offset:{i*2048}")
+    L.append("s_waitcnt lgkmcnt(0)")
+    r1 = [f"ds_read_b128 v[{FB[1]+4*j}:{FB[1]+4*j+3}], %[cb1] offset:{j*2048}" for j in range(4)] + \
+         [f"ds_read_b128 v[{FA[1]+4*i}:{FA[1]+4*i+3}], %[ca1] offset:{i*2048}" for i in range(8)]
+    L += interleave([mfma(op, i, j, 0) for (i, j) in order], [(k, [r]) for k, r in enumerate(r1)])
+    L.append("s_waitcnt lgkmcnt(0)")
+    L += [mfma(op, i, j, 1) for (i, j) in order]
+    L += ["s_nop 7"]
+    return L
+
+
 def emit(f):
     f.write("// GENERATED by tools/gen_conv_asm.py - do not edit (register map, schedule and the reasons: that file)\n")
     # accumulator tile T of this lane (a[4T : 4T+3]) out of the accumulator file, one specialisation per tile (register names are text)
@@ -155,6 +174,11 @@ def emit(f):
                 f'asm volatile("v_accvgpr_read_b32 %0, a{4*t}\\n\\tv_accvgpr_read_b32 %1, a{4*t+1}\\n\\tv_accvgpr_read_b32 %2, a{4*t+2}\\n\\tv_accvgpr_read_b32 %3, a{4*t+3}" '
                 f': "=v"(a), "=v"(b), "=v"(c), "=v"(d)); return f32x4_t{{a, b, c, d}}; }}\n')
     f.write("\n")
+    f.write("#define CONV_ASM_ZERO_ACC \\\n" + " \\\n".join(f'  "v_accvgpr_write_b32 a{a}, 0\\n\\t"' for a in range(128)) + "\n\n")
+    for tname, op in (("BF16", "v_mfma_f32_16x16x32_bf16"), ("F16", "v_mfma_f32_16x16x32_f16")):
+        f.write(f"#define CONV_ASM_CHAIN2_{tname} \\\n")
+        f.write(" \\\n".join(f'  "{l}\\n\\t"' for l in chain2_text(op)))
+        f.write("\n\n")
     # one text per (operand type, masked / unmasked staging, m-tiles of the wave group, A passes of the tile): the tile is 16 (MT0 + MT1) rows,
     # wave group 0 (waves 0-3) owns the first MT0 m-tiles, group 1 the next MT1 (a SIMD holds one wave of each: MT0 + MT1 MFMA rows per SIMD)
     done = set()

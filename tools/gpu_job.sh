@@ -84,6 +84,11 @@ PY
       python tools/pmc_summary.py $O/v$v conv_gemm > $O/pmc_3x3_512ch_20x20_variant$v.txt; rm -rf $O/v$v
       head -40 $O/pmc_3x3_512ch_20x20_variant$v.txt
     done ;;
+  chain6)      # round 6: the chained pairs on the asm K loop (variant 0) against the 16-wave chained kernel (97): tests, per-pair timing, whole forward
+    timeout 1500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -q -m gpu -x -k "chain" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -4 $O/tests.log
+    for v in 97 0 97 0; do echo "variant $v"; CFT_CHAIN_BENCH_VARIANT=$v timeout 300 python tools/chain_bench.py --res 2>&1 | tail -3; CFT_CHAIN_BENCH_VARIANT=$v timeout 300 python tools/chain_bench.py 2>&1 | grep -E "256|bf16" | tail -4; done | tee $O/chain_bench.txt
+    X="--no-cpu-baseline --no-f16-leg --no-parity --sustained-steps 0"
+    for v in 97 0 97 0; do timeout 300 python bench.py $X --conv-variant $v > $O/bench_v$v.json 2>> $O/bench.log; python -c "import json;d=json.load(open('$O/bench_v$v.json'));print('variant $v', d['value'], d['ms_per_step'], d['roofline']['frac'], (d.get('single_in_flight') or {}).get('value'))" | tee -a $O/summary.txt; done ;;
   micro)       # micro-benchmarks: HBM read / write / copy ceilings; Infinity-Cache producer -> consumer; DMA stream coupling; power coupling
     for m in ${@:-hbm_rw mall_probe dma_ring power_coupling}; do timeout 200 tools/micro/$m > $O/$m.txt 2>&1; echo "$m rc=$?"; tail -40 $O/$m.txt; done ;;
   r5a)         # round 5, first call: Infinity-Cache probe; new tests (depth-first prefix, survey weights, ADVICE fixes); depth-first A/B on the forward
