@@ -404,3 +404,42 @@ def test_splitk_choice_rule():
     assert ops.splitk_choice(1024, pk(4096, 1024), torch.bfloat16) == 1          # wide N: 64 tiles already
     assert ops.splitk_choice(1024, pk(1024, 1000), torch.bfloat16) == 1          # K not on the uniform walk (padded)
     assert ops.splitk_choice(512, pk(1024, 4096), torch.float32) == 8            # fp32: 32-wide K steps
+
+
+@pytest.mark.parametrize("gen, inc", [("tools/gen_conv_asm.py", "multispectral-object-detection_amd/csrc/conv_gemm_asm.inc"),
+                                      ("tools/gen_bneck_asm.py", "multispectral-object-detection_amd/csrc/probes/bottleneck_asm.inc")])
+def test_committed_asm_text_is_what_its_generator_writes(gen, inc, tmp_path):
+    """The hand-scheduled K loops are GENERATED text (csrc/*.inc, committed so that a build needs no generator run): the committed file must
+    be byte-for-byte what the committed generator writes - an edit of one without the other fails here, not on the GPU."""
+    import subprocess
+    import sys
+    out = tmp_path / "gen.inc"
+    subprocess.run([sys.executable, os.path.join(ROOT, gen), str(out)], check=True, env={**os.environ, "CONV_ASM_PAD_NOPS": "0"})
+    assert out.read_bytes() == open(os.path.join(ROOT, inc), "rb").read()
+
+
+def test_asm_loop_text_invariants():
+    """Structural invariants of one generated K step (tools/gen_conv_asm.py): 64 MFMAs, 24 fragment reads, AP + 4 LDS-DMA requests, exactly
+    one barrier, and every accumulator register of the (MT0 / MT1) m-tiles written exactly twice per step (k halves 0 and 1)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_conv_asm", os.path.join(ROOT, "tools", "gen_conv_asm.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    op = "v_mfma_f32_16x16x32_bf16"
+    for (mt0, mt1) in g.TILES:
+        ap = (16 * (mt0 + mt1) + 63) // 64                    # A passes of the tile (emit())
+        for grp, mt in ((0, mt0), (1, mt1)):
+            for masked in (False, True):
+                for c in (0, 1):
+                    lines = [ln for item in g.step(op, c, grp, masked, mt, ap) for ln in ([item] if isinstance(item, str) else item)]
+                    mf = [ln for ln in lines if ln.startswith(op)]
+                    assert len(mf) == 8 * mt, (mt, masked, grp)
+                    accs = [ln.split()[1].rstrip(",") for ln in mf]
+                    assert all(accs.count(a) == 2 for a in set(accs)) and len(set(accs)) == 4 * mt
+                    assert sum(ln.startswith("ds_read_b128") for ln in lines) == 2 * (mt + 4)
+                    assert sum(ln.startswith("s_barrier") for ln in lines) == 1
+                    assert sum(ln.startswith("buffer_load_dwordx4") for ln in lines) == ap + 4
+                    # the barrier sits between the two MFMA halves, behind a full wait
+                    b = next(i for i, ln in enumerate(lines) if ln.startswith("s_barrier"))
+                    assert lines[b - 1] == "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                    assert sum(ln.startswith(op) for ln in lines[:b]) == 4 * mt
