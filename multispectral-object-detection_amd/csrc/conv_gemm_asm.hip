@@ -503,9 +503,12 @@ __global__ void __launch_bounds__(512) conv_gemm_asm_chain_kernel(const ConvAsmP
   p2.N = pe.N2;
   p2.res = nullptr;
   const int row0 = wm * 128;
-  if (p2.act == CFT_ACT_SILU) conv_epilogue_agpr<T, CFT_ACT_SILU, false, 8>(p2, smem, m0, 0, row0, wn, wave, lane, bias2_v);
-  else if (p2.act == CFT_ACT_GELU) conv_epilogue_agpr<T, CFT_ACT_GELU, false, 8>(p2, smem, m0, 0, row0, wn, wave, lane, bias2_v);
-  else conv_epilogue_agpr<T, CFT_ACT_NONE, false, 8>(p2, smem, m0, 0, row0, wn, wave, lane, bias2_v);
+  int tid3 = threadIdx.x;                                // (the lane index once more from the thread id: kept across the four blocks above it spills)
+  asm volatile("" : "+v"(tid3));
+  const int lane3 = tid3 & 63;
+  if (p2.act == CFT_ACT_SILU) conv_epilogue_agpr<T, CFT_ACT_SILU, false, 8>(p2, smem, m0, 0, row0, wn, wave, lane3, bias2_v);
+  else if (p2.act == CFT_ACT_GELU) conv_epilogue_agpr<T, CFT_ACT_GELU, false, 8>(p2, smem, m0, 0, row0, wn, wave, lane3, bias2_v);
+  else conv_epilogue_agpr<T, CFT_ACT_NONE, false, 8>(p2, smem, m0, 0, row0, wn, wave, lane3, bias2_v);
 }
 
 // ------------------------------------------------------------------------------------ host

@@ -84,6 +84,14 @@ PY
       python tools/pmc_summary.py $O/v$v conv_gemm > $O/pmc_3x3_512ch_20x20_variant$v.txt; rm -rf $O/v$v
       head -40 $O/pmc_3x3_512ch_20x20_variant$v.txt
     done ;;
+  pmc6b)       # round 6: counters VERDICT r5 listed as evidence gaps - the shipped bottleneck128c_kernel, and the d = 1024 CFT linears at M = 8 192 (asm kernel, 128-row tiles)
+    bash tools/pmc.sh $O/b128 -- python tools/bneck_bench.py 128 0 > $O/pmc_b128.log 2>&1
+    python tools/pmc_summary.py $O/b128 bottleneck128c > $O/pmc_bottleneck128c.txt; rm -rf $O/b128; head -40 $O/pmc_bottleneck128c.txt
+    for shape in "GPT fc2 4096->1024" "GPT qkv 1024->3072"; do
+      tag=$(echo "$shape" | tr ' >' '__' | tr -d '-()=')
+      bash tools/pmc.sh $O/lin -- python tools/gemm_bench.py --variants 0 --iters 10 --rounds 1 --only "$shape" --out $JOB/lin.json > $O/pmc_$tag.log 2>&1
+      python tools/pmc_summary.py $O/lin conv_gemm > $O/pmc_$tag.txt; rm -rf $O/lin; head -40 $O/pmc_$tag.txt
+    done ;;
   chain6)      # round 6: the chained pairs on the asm K loop (variant 0) against the 16-wave chained kernel (97): tests, per-pair timing, whole forward
     timeout 1500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -q -m gpu -x -k "chain" > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -4 $O/tests.log
     for v in 97 0 97 0; do echo "variant $v"; CFT_CHAIN_BENCH_VARIANT=$v timeout 300 python tools/chain_bench.py --res 2>&1 | tail -3; CFT_CHAIN_BENCH_VARIANT=$v timeout 300 python tools/chain_bench.py 2>&1 | grep -E "256|bf16" | tail -4; done | tee $O/chain_bench.txt
