@@ -88,7 +88,7 @@ PY
     bash tools/pmc.sh $O/b128 -- python tools/bneck_bench.py 128 0 > $O/pmc_b128.log 2>&1
     python tools/pmc_summary.py $O/b128 bottleneck128c > $O/pmc_bottleneck128c.txt; rm -rf $O/b128; head -40 $O/pmc_bottleneck128c.txt
     for shape in "GPT fc2 4096->1024" "GPT qkv 1024->3072"; do
-      tag=$(echo "$shape" | tr ' >' '__' | tr -d '-()=')
+      tag=$(echo "$shape" | sed -e 's/[^A-Za-z0-9]\+/_/g')
       bash tools/pmc.sh $O/lin -- python tools/gemm_bench.py --variants 0 --iters 10 --rounds 1 --only "$shape" --out $JOB/lin.json > $O/pmc_$tag.log 2>&1
       python tools/pmc_summary.py $O/lin conv_gemm > $O/pmc_$tag.txt; rm -rf $O/lin; head -40 $O/pmc_$tag.txt
     done ;;
