@@ -681,6 +681,8 @@ def main():
                 line["parity_green_value"] = line["f16"]["value"]
             line["parity_weights"] = "utils/seeded.seeded_state_dict (deliberately lively stress weights: activations O(1) through the depth)"
             if world == 1:
+                # (the oracle legs below at the thread count the cpu_baseline sweep found best: torch's default on a 256-thread host is 3-5 x slower)
+                torch.set_num_threads(getattr(cpu_baseline, "best_threads", min(16, os.cpu_count() or 8)))
                 # the contract's own weights: the timed dtype, literal bound; a miss fails the run like any parity miss
                 line["parity_at_bench_shape_survey_weights"] = sp = survey_weights_parity(cfg, args, dev, dtype, rgb, ir)
                 ok = ok and sp["ok"]
