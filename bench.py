@@ -447,7 +447,7 @@ def main():
         # N > 1: the all-gather of step i runs on RCCL's stream while the forward of step i+1 runs on the compute
         # stream (51.6 MB per rank per step would otherwise add ~10 % serial time); see distributed.OverlappedGather.
         gather = D.OverlappedGather(pred, world) if gathering else None
-        # A step = one forward over one batch of `--batch` pairs.  With --in-flight K (default 2) step t replays graph t % K on HIP
+        # A step = one forward over one batch of `--batch` pairs.  With --in-flight K (default 3 at >= 32 pairs per GPU, 4 below) step t replays graph t % K on HIP
         # stream t % K: consecutive steps are independent batches and overlap on the GPU (distributed.ForwardPipeline) - the
         # low-occupancy stretches of one forward (CFT blocks with M = 8192, the single-stream head) run under the other's
         # backbone convolutions.  --in-flight 1 = one forward at a time (also reported as "single_in_flight").
