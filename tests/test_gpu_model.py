@@ -407,7 +407,7 @@ def test_three_single_stream_forwards_in_flight_are_bit_stable_at_the_benchmarke
     through distributed.ForwardPipeline at the benchmarked shape (64 pairs, 640 x 640, bf16: the asm GEMM kernels, the chained asm pairs and
     the fused Bottlenecks all run, three kernels of different forwards at a time).  Every replay of every graph must reproduce, bit for bit,
     what the two-stream graph computes alone - a missing wait or barrier in a hand-scheduled loop shows up as a rare mismatch under exactly
-    this kind of co-scheduling."""
+    this kind of co-scheduling.  On the way: the eager forward with the asm kernels switched off (variant 97) equals the default bit for bit."""
     from msod_amd import distributed as D
     from msod_amd.graph import CapturedForward
     from msod_amd.utils.seeded import seeded_inputs
@@ -420,6 +420,20 @@ def test_three_single_stream_forwards_in_flight_are_bit_stable_at_the_benchmarke
         pred0, raw0 = model(x, x2)
         torch.cuda.synchronize()
         pred0, raw0 = pred0.clone(), [r.clone() for r in raw0]
+        # the same forward without the hand-scheduled kernels (variant 97 = the round-5 choice: 16-wave kernels, 16-wave chained pairs): every asm
+        # kernel is bit-identical to the kernel it replaces, so the whole forward must be
+        from msod_amd import _lib
+        lib = _lib.load()
+        old = lib.cft_set_conv_variant(97)
+        try:
+            pred97, raw97 = model.forward_once(x, x2)
+            torch.cuda.synchronize()
+        finally:
+            lib.cft_set_conv_variant(old)
+        assert torch.equal(pred97, pred0)
+        for a, b in zip(raw97, raw0):
+            assert torch.equal(a, b)
+        del pred97, raw97
         model.overlap_streams = False                     # (drops the two-stream graph)
         caps = [CapturedForward(model, 64, 640, 640) for _ in range(3)]
         for c in caps:
